@@ -1,0 +1,183 @@
+/* tardis_mc.h -- C ABI of the MI355X-native Monte Carlo packet-propagation engine (libtardis_mc_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of tardis-sn/tardis: the Monte Carlo main loop
+ *     montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, time_explosion,
+ *         opacity_state_numba, montecarlo_configuration, spectrum_frequency_grid, trackers,
+ *         number_of_vpackets, show_progress_bars, packet_propagation_function)
+ *       -> (v_packets_energy_hist, vpacket_tracker, estimators_bulk, estimators_line)
+ *     tardis/transport/montecarlo/modes/montecarlo_transport.py:238-373
+ * as called from MCTransportSolverClassic.run_classic
+ *     tardis/transport/montecarlo/modes/classic/solver.py:223-234.
+ * The reference has no FFI for this path (it is a Numba @njit function), so these entry points are what a
+ * ctypes binding inside run_classic would bind; see INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all reals are float64, all integers int64 (the reference's dtypes);
+ *   - every array is caller-owned, C-contiguous, and is neither retained nor freed by the library after
+ *     the call that takes it returns (inputs are copied to HBM; outputs are written in place);
+ *   - 2-D arrays use the REFERENCE's layout: tau_sobolev[L,S], transition_probabilities[T,S],
+ *     j_blue[L,S], Edotlu[L,S], row-major (line index slow, shell index fast).  The engine keeps its own
+ *     shell-major copies in HBM;
+ *   - functions return 0 on success or a negative TARDIS_MC_ERR_* code; tardis_mc_last_error() gives text;
+ *   - a context is bound to one HIP device and one stream; entry points are not re-entrant per context.
+ */
+#ifndef TARDIS_MC_H
+#define TARDIS_MC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TARDIS_MC_ABI_VERSION 1
+
+enum {
+    TARDIS_MC_OK = 0,
+    TARDIS_MC_ERR_INVALID_ARGUMENT = -1,
+    TARDIS_MC_ERR_HIP = -2,          /* HIP runtime failure (no device, OOM, launch failure) */
+    TARDIS_MC_ERR_MONTECARLO = -3,   /* reference: MonteCarloException("nu difference is less than 0.0"),
+                                        transport/geometry/calculate_distances.py:105-106 */
+    TARDIS_MC_ERR_MACRO_ATOM = -4,   /* reference: MacroAtomError, transport/montecarlo/macro_atom.py:94-99 */
+    TARDIS_MC_ERR_UNSUPPORTED = -5,  /* transition type outside classic mode (continuum processes) */
+    TARDIS_MC_ERR_COMM = -6,         /* RCCL failure */
+    TARDIS_MC_ERR_STATE = -7         /* call order violated (e.g. propagate before set_opacity) */
+};
+
+/* LineInteractionType, transport/montecarlo/interaction_events.py:220-223 */
+enum { TARDIS_MC_LINE_SCATTER = 0, TARDIS_MC_LINE_DOWNBRANCH = 1, TARDIS_MC_LINE_MACROATOM = 2 };
+
+/* MonteCarloConfiguration fields the classic path reads, transport/montecarlo/configuration/base.py:11-49,
+ * plus SIGMA_THOMSON (configuration/constants.py:3; 1e-200 when electron scattering is disabled,
+ * modes/classic/solver.py:291-300). */
+typedef struct TardisMcConfig {
+    int32_t enable_full_relativity;        /* ENABLE_FULL_RELATIVITY */
+    int32_t line_interaction_type;         /* LINE_INTERACTION_TYPE */
+    int32_t disable_line_scattering;       /* DISABLE_LINE_SCATTERING */
+    int32_t enable_vpacket_tracking;       /* ENABLE_VPACKET_TRACKING */
+    int64_t number_of_vpackets;            /* NUMBER_OF_VPACKETS */
+    double survival_probability;           /* SURVIVAL_PROBABILITY (default 0.0) */
+    double vpacket_tau_russian;            /* VPACKET_TAU_RUSSIAN (default 10.0) */
+    double vpacket_spawn_start_frequency;  /* VPACKET_SPAWN_START_FREQUENCY */
+    double vpacket_spawn_end_frequency;    /* VPACKET_SPAWN_END_FREQUENCY */
+    double sigma_thomson;                  /* SIGMA_THOMSON [cm^2] */
+    int64_t n_spectrum_grid;               /* len(spectrum_frequency_grid) = bins + 1 */
+    const double *spectrum_frequency_grid; /* uniform ascending edges [Hz] */
+} TardisMcConfig;
+
+/* PacketCollection inputs, transport/montecarlo/packets/packet_collections.py:14-76 */
+typedef struct TardisMcPackets {
+    int64_t n_packets;
+    const double *initial_radii;
+    const double *initial_nus;
+    const double *initial_mus;
+    const double *initial_energies;
+    const int64_t *packet_seeds;           /* MT19937 init_genrand seed per packet, in [0, 2^32-2] */
+} TardisMcPackets;
+
+/* NumbaHomologousRadial1DGeometry, model/geometry/radial1d_homologous.py:199-226 */
+typedef struct TardisMcGeometry {
+    int64_t n_shells;
+    const double *r_inner;
+    const double *r_outer;
+    double time_explosion;
+} TardisMcGeometry;
+
+/* OpacityStateNumba fields used by classic mode, opacities/opacity_state_numba.py:14-196 */
+typedef struct TardisMcOpacity {
+    int64_t n_lines;                       /* L */
+    int64_t n_shells;                      /* S */
+    int64_t n_transitions;                 /* T (1 for "scatter" dummies) */
+    int64_t n_macro_block_edges;           /* len(macro_block_edge_index) = levels + 1 */
+    const double *electron_density;        /* [S] */
+    const double *line_list_nu;            /* [L] descending */
+    const double *tau_sobolev;             /* [L,S] */
+    const double *transition_probabilities;/* [T,S] */
+    const int64_t *line2macro_level_upper; /* [L] */
+    const int64_t *macro_block_edge_index; /* [levels+1] */
+    const int64_t *transition_type;        /* [T] */
+    const int64_t *destination_level_id;   /* [T] */
+    const int64_t *transition_line_id;     /* [T] */
+} TardisMcOpacity;
+
+/* Work counters accumulated by the kernels (bytes = 48 V + 56 E + 8 M + 16 Vv + 56 P) */
+enum {
+    TARDIS_MC_CNT_LINE_VISITS = 0,         /* V: iterations of the trace_packet line loop */
+    TARDIS_MC_CNT_EVENTS = 1,              /* E: trace_packet calls */
+    TARDIS_MC_CNT_MACRO_TRANSITIONS = 2,   /* M: transition probabilities examined */
+    TARDIS_MC_CNT_VPACKET_LINE_VISITS = 3, /* Vv */
+    TARDIS_MC_CNT_VPACKETS = 4,            /* v-packets traced */
+    TARDIS_MC_CNT_RNG_DRAWS = 5,           /* MT19937 doubles consumed */
+    TARDIS_MC_CNT_PACKETS = 6,             /* P */
+    TARDIS_MC_CNT_RESERVED = 7,
+    TARDIS_MC_N_COUNTERS = 8
+};
+
+/* Outputs.  Any pointer may be NULL to skip that output (sizes in comments). */
+typedef struct TardisMcResult {
+    double *output_nus;                    /* [P]  packet_collection.output_nus */
+    double *output_energies;               /* [P]  +e EMITTED / -e REABSORBED (montecarlo_transport.py:70-90) */
+    double *j_estimator;                   /* [S]  EstimatorsBulk.mean_intensity_total */
+    double *nu_bar_estimator;              /* [S]  EstimatorsBulk.mean_frequency */
+    double *j_blue_estimator;              /* [L,S] EstimatorsLine.mean_intensity_blueward */
+    double *edotlu_estimator;              /* [L,S] EstimatorsLine.energy_deposition_line_rate */
+    double *v_packets_energy_hist;         /* [n_spectrum_grid] */
+    /* TrackerLastInteraction as SoA, packets/trackers/tracker_last_interaction.py:8-254 */
+    double *li_radius, *li_nu, *li_energy;                 /* [P] each */
+    double *li_before_nu, *li_before_mu, *li_before_energy;
+    double *li_after_nu, *li_after_mu, *li_after_energy;
+    int64_t *li_shell_id, *li_interaction_type;
+    int64_t *li_line_absorb_id, *li_line_emit_id, *li_interactions_count;
+    /* consolidated v-packet log (only when enable_vpacket_tracking), packet order */
+    int64_t vpacket_log_capacity;          /* in: entries available in the four arrays below */
+    int64_t vpacket_log_count;             /* out: entries produced (may exceed capacity -> truncated) */
+    double *vpacket_nus, *vpacket_energies, *vpacket_initial_mus, *vpacket_initial_rs;
+    int64_t counters[TARDIS_MC_N_COUNTERS];
+    int64_t first_error_packet;            /* out: lowest packet index that failed, or -1 */
+    int32_t error_code;                    /* out: 0 or TARDIS_MC_ERR_MONTECARLO / _MACRO_ATOM / _UNSUPPORTED */
+    int32_t reserved;
+} TardisMcResult;
+
+typedef struct TardisMcContext TardisMcContext;
+
+/* ---- library / device ---------------------------------------------------------------------------- */
+int tardis_mc_abi_version(void);
+int tardis_mc_device_count(void);
+/* Create a context on HIP device `device_id` (one process per GPU: pass LOCAL_RANK). */
+int tardis_mc_create(int device_id, TardisMcContext **out_ctx);
+void tardis_mc_destroy(TardisMcContext *ctx);
+const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NULL: last create() error */
+
+/* ---- staged API: inputs resident in HBM, kernels timed separately -------------------------------- */
+int tardis_mc_set_geometry(TardisMcContext *ctx, const TardisMcGeometry *geometry);
+/* Uploads and re-lays the opacity tables shell-major; once per MC iteration (the plasma changes them). */
+int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *opacity);
+int tardis_mc_set_config(TardisMcContext *ctx, const TardisMcConfig *config);
+int tardis_mc_set_packets(TardisMcContext *ctx, const TardisMcPackets *packets);
+/* Zero J, nu_bar, j_blue, Edotlu, v-hist and the counters (start of an iteration). */
+int tardis_mc_reset_estimators(TardisMcContext *ctx);
+/* Launch the propagation kernels for the resident packets on the context stream (asynchronous).
+ * Estimators ACCUMULATE across calls until tardis_mc_reset_estimators (packet chunks of one iteration). */
+int tardis_mc_propagate(TardisMcContext *ctx);
+int tardis_mc_synchronize(TardisMcContext *ctx);
+/* Device time of the kernels launched by the last tardis_mc_propagate (HIP events on the ctx stream). */
+int tardis_mc_last_propagate_ms(TardisMcContext *ctx, double *out_ms);
+/* Per-packet results of the resident packets + estimators (re-laid to [L,S]) to caller memory. */
+int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *result);
+
+/* ---- one-shot API: the reference boundary in one call ---------------------------------------------- */
+int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const TardisMcGeometry *geometry,
+                  const TardisMcOpacity *opacity, const TardisMcConfig *config, TardisMcResult *result);
+
+/* ---- multi-GPU: packets shard by index, one all-reduce of the estimators per iteration (RCCL) ----- */
+#define TARDIS_MC_UNIQUE_ID_BYTES 128
+int tardis_mc_comm_get_unique_id(uint8_t out_id[TARDIS_MC_UNIQUE_ID_BYTES]);
+int tardis_mc_comm_init(TardisMcContext *ctx, int rank, int world_size,
+                        const uint8_t id[TARDIS_MC_UNIQUE_ID_BYTES]);
+/* In-place sum over ranks of J, nu_bar, j_blue, Edotlu, v-hist (device buffers), on the ctx stream. */
+int tardis_mc_allreduce_estimators(TardisMcContext *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TARDIS_MC_H */

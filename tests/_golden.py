@@ -1,0 +1,51 @@
+"""Helpers to load the reference-generated fixtures (tests/golden/*.npz, made by tools/make_golden.py).
+
+A fixture holds the inputs the reference ran on and the outputs it produced; nothing is regenerated.
+"""
+import json
+import os
+
+import numpy as np
+
+from tardis_amd import state as st
+from tardis_amd import synthetic
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz") and f != "libm_probe.npz")
+
+
+def load_case(name):
+    """Returns (problem, golden dict)."""
+    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+    pc = st.PacketCollection(g["in_initial_radii"], g["in_initial_nus"], g["in_initial_mus"],
+                             g["in_initial_energies"], g["in_packet_seeds"], float(g["in_radiation_field_luminosity"]))
+    geo = st.HomologousRadial1DGeometry(g["in_r_inner"], g["in_r_outer"], g["in_v_inner"], g["in_v_outer"],
+                                        float(g["in_time_explosion"]))
+    tau = g["in_tau0"] if g["in_tau_rho"].size == 0 else g["in_tau0"][:, None] * g["in_tau_rho"][None, :]
+    prob_t = g["in_transition_probabilities"]
+    if prob_t.shape[1] == 1 and len(g["in_electron_density"]) > 1:  # shell-independent probabilities stored once
+        prob_t = np.repeat(prob_t, len(g["in_electron_density"]), axis=1)
+    op = st.OpacityState(g["in_electron_density"], np.zeros(len(g["in_electron_density"])), g["in_line_list_nu"], tau,
+                         prob_t, g["in_line2macro_level_upper"],
+                         g["in_macro_block_edge_index"], g["in_transition_type"], g["in_destination_level_id"],
+                         g["in_transition_line_id"])
+    cfg = st.MonteCarloConfiguration()
+    for k, v in json.loads(str(g["config"])).items():
+        if v is not None:
+            setattr(cfg, k, v)
+    prob = synthetic.Problem(pc, geo, geo.time_explosion, op, cfg, g["in_spectrum_frequency_grid"], name)
+    return prob, g
+
+
+TRACKER_F64 = ("radius", "nu", "energy", "before_nu", "before_mu", "before_energy", "after_nu", "after_mu",
+               "after_energy")
+TRACKER_I64 = ("shell_id", "interaction_type", "interaction_line_absorb_id", "interaction_line_emit_id",
+               "interactions_count")
+
+
+def max_rel(a, b):
+    """max |a-b|/|b| over b != 0, and exact agreement required where b == 0."""
+    a, b = np.asarray(a), np.asarray(b)
+    m = b != 0
+    assert np.array_equal(a[~m], b[~m])
+    return float(np.max(np.abs(a[m] - b[m]) / np.abs(b[m]))) if m.any() else 0.0
