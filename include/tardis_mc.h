@@ -148,6 +148,11 @@ int tardis_mc_create(int device_id, TardisMcContext **out_ctx);
 void tardis_mc_destroy(TardisMcContext *ctx);
 const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NULL: last create() error */
 
+/* Tunables.  name: "track_last_interaction" (0/1, default 1), "vpacket_log_capacity" (entries),
+ * "variant" (kernel variant id), "blocks_per_cu", "estimator_copies" (1..8 private j_blue/Edotlu copies),
+ * "debug_flags" (profiling experiments only: 1 skips the j_blue/Edotlu atomics, 2 the J/nu_bar updates). */
+int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value);
+
 /* ---- staged API: inputs resident in HBM, kernels timed separately -------------------------------- */
 int tardis_mc_set_geometry(TardisMcContext *ctx, const TardisMcGeometry *geometry);
 /* Uploads and re-lays the opacity tables shell-major; once per MC iteration (the plasma changes them). */
@@ -176,6 +181,15 @@ int tardis_mc_comm_init(TardisMcContext *ctx, int rank, int world_size,
                         const uint8_t id[TARDIS_MC_UNIQUE_ID_BYTES]);
 /* In-place sum over ranks of J, nu_bar, j_blue, Edotlu, v-hist (device buffers), on the ctx stream. */
 int tardis_mc_allreduce_estimators(TardisMcContext *ctx);
+
+/* ---- diagnostics: element-wise device arithmetic, used by the numerics parity tests ------------------
+ * op: 0 x+y, 1 x*y, 2 x/y, 3 sqrt(x), 4 log(x) [engine's portable log], 5 exp(x), 6 x*y+x (un-fused),
+ *     7 MT19937 doubles of seed (uint32)x[0] (n outputs), 8 floor(x). */
+int tardis_mc_debug_eval(TardisMcContext *ctx, int op, const double *x, const double *y, double *out, int64_t n);
+/* Memory-system micro-benchmarks used to size the kernels (design input): which = 0 random fp64 atomics (agent
+ * scope), 1 same at workgroup scope in a per-XCD slice, 2/3 the same with 16 consecutive doubles per 16 lanes,
+ * 4 random 8-byte loads, 5 16-lane-coalesced loads.  blocks x 256 threads x iters operations; time in ms. */
+int tardis_mc_debug_microbench(TardisMcContext *ctx, int which, int64_t n_doubles, int iters, int blocks, double *out_ms);
 
 #ifdef __cplusplus
 }

@@ -63,8 +63,22 @@ def lib():
     return _lib
 
 
-def max_threads() -> int:
-    return int(lib().oracle_max_threads())
+def max_threads(cap: int = 64) -> int:
+    """Threads worth using for the OpenMP oracle: OpenMP's maximum, clipped by the CPU affinity mask, the cgroup CPU
+    quota of the container (oversubscribing a quota-limited pod is far slower than using fewer threads) and `cap`."""
+    n = int(lib().oracle_max_threads())
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
 
 
 def run(packet_collection, geometry, time_explosion, opacity_state, montecarlo_configuration,

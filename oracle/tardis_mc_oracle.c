@@ -615,8 +615,17 @@ int oracle_mc_run(const TardisMcPackets *pk, const TardisMcGeometry *geo, const 
     if (!ed) { ed = (double *)calloc((size_t)L * S, 8); own_ed = 1; } else memset(ed, 0, (size_t)L * S * 8);
     if (!hist) { hist = (double *)calloc(G > 0 ? G : 1, 8); own_h = 1; } else memset(hist, 0, G * 8);
 
+    /* n_threads > 1: per-thread private estimator copies reduced at the end -- the reference's own scheme
+     * (montecarlo_transport.py:309-314,356-360) -- while they fit in 16 GiB; otherwise omp atomics. */
+    const size_t est_elems = (size_t)2 * S + (size_t)2 * L * S;
+    int use_private = n_threads > 1 && (double)est_elems * 8.0 * n_threads <= 16.0 * 1024 * 1024 * 1024;
+    double *priv = NULL;
+    if (use_private) {
+        priv = (double *)calloc(est_elems * (size_t)n_threads, 8);
+        if (!priv) use_private = 0;
+    }
     run_ctx c;
-    c.geo = geo; c.op = op; c.cfg = cfg; c.math_mode = math_mode; c.atomic = n_threads > 1;
+    c.geo = geo; c.op = op; c.cfg = cfg; c.math_mode = math_mode; c.atomic = (n_threads > 1) && !use_private;
     c.J = J; c.nubar = nubar; c.jblue = jb; c.edot = ed;
     const double delta_nu = G >= 2 ? cfg->spectrum_frequency_grid[1] - cfg->spectrum_frequency_grid[0] : 1.0;
     const int track_v = cfg->enable_vpacket_tracking && cfg->number_of_vpackets > 0;
@@ -637,6 +646,15 @@ int oracle_mc_run(const TardisMcPackets *pk, const TardisMcGeometry *geo, const 
         mt_state rng;
         vlist local;
         memset(&local, 0, sizeof local);
+        run_ctx tc = c; /* thread-local view: private estimator block when use_private */
+        if (use_private) {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            double *b = priv + est_elems * (size_t)tid;
+            tc.J = b; tc.nubar = b + S; tc.jblue = b + 2 * S; tc.edot = b + 2 * S + (size_t)L * S;
+        }
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 64)
 #endif
@@ -650,7 +668,7 @@ int oracle_mc_run(const TardisMcPackets *pk, const TardisMcGeometry *geo, const 
             tracker_init(&trk);
             vlist *vl = track_v ? &vlists[i] : &local;
             vl->n = 0;
-            int err = packet_propagation(&c, &p, &rng, &trk, vl, &cn);
+            int err = packet_propagation(&tc, &p, &rng, &trk, vl, &cn);
             cn.c[TARDIS_MC_CNT_RNG_DRAWS] += rng.draws;
             if (err) {
 #ifdef _OPENMP
@@ -684,7 +702,11 @@ int oracle_mc_run(const TardisMcPackets *pk, const TardisMcGeometry *geo, const 
                 double nu = vl->nus[j];
                 if (nu < cfg->spectrum_frequency_grid[0] || nu > cfg->spectrum_frequency_grid[G - 1]) continue;
                 int64_t idx = (int64_t)floor((nu - cfg->spectrum_frequency_grid[0]) / delta_nu);
-                add_to(&c, &hist[idx], vl->energies[j]);
+                if (n_threads > 1) {
+#pragma omp atomic
+                    hist[idx] += vl->energies[j];
+                } else
+                    hist[idx] += vl->energies[j];
             }
         }
         free(local.nus); free(local.energies); free(local.mus); free(local.rs);
@@ -692,6 +714,18 @@ int oracle_mc_run(const TardisMcPackets *pk, const TardisMcGeometry *geo, const 
 #pragma omp critical
 #endif
         for (int k = 0; k < TARDIS_MC_N_COUNTERS; ++k) total.c[k] += cn.c[k];
+    }
+    if (use_private) { /* estimators.increment(thread copy) for every thread */
+        for (int t = 0; t < n_threads; ++t) {
+            const double *b = priv + est_elems * (size_t)t;
+            for (int64_t k = 0; k < S; ++k) { J[k] += b[k]; nubar[k] += b[S + k]; }
+            const double *bj = b + 2 * S, *be = b + 2 * S + (size_t)L * S;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads)
+#endif
+            for (int64_t k = 0; k < L * S; ++k) { jb[k] += bj[k]; ed[k] += be[k]; }
+        }
+        free(priv);
     }
     total.c[TARDIS_MC_CNT_PACKETS] = P;
     memcpy(res->counters, total.c, sizeof total.c);

@@ -1,0 +1,209 @@
+// mc_device.hpp -- device-side data model and leaf physics of the MC packet engine (gfx950).
+//
+// Scalar per-packet physics written to reproduce the reference's floating-point operation order exactly
+// (IEEE double, no FMA contraction: the translation unit is compiled with -ffp-contract=off), so that the
+// per-packet results are bit-identical to the CPU oracle.  Reference lines are cited at each function.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mc_math.hpp"
+
+namespace mc {
+
+constexpr double C_LIGHT = 2.99792458e10;       // tardis/constants.py:1 (CODATA 2010)
+constexpr double CLOSE_LINE_THRESHOLD = 1e-14;  // configuration/constants.py:4
+constexpr double MISS_DISTANCE = 1e99;          // configuration/constants.py:6
+
+enum : int { IT_BOUNDARY = 1, IT_LINE = 2, IT_ESCATTERING = 4 };
+enum : int { ST_IN_PROCESS = 0, ST_EMITTED = 1, ST_REABSORBED = 2 };
+enum : int { ERR_MONTECARLO = -3, ERR_MACRO_ATOM = -4, ERR_UNSUPPORTED = -5 };
+
+constexpr int MT_N = 624;
+
+// Everything a propagation kernel needs, passed by value (kernarg segment -> SGPRs).
+struct DeviceProblem {
+    // packets (SoA, coalesced by packet index)
+    long long n_packets;
+    const double *r0, *mu0, *nu0, *e0;
+    const uint32_t *seeds;
+    double *out_nu, *out_e;
+    // last-interaction tracker SoA (all null when tracking is off)
+    double *li_radius, *li_nu, *li_energy, *li_before_nu, *li_before_mu, *li_before_energy, *li_after_nu,
+        *li_after_mu, *li_after_energy;
+    long long *li_shell_id, *li_interaction_type, *li_line_absorb_id, *li_line_emit_id, *li_interactions_count;
+    // geometry
+    int n_shells;
+    const double *r_inner, *r_outer;
+    double t_exp;
+    // opacity (shell-major tables)
+    int n_lines, n_trans;
+    const double *nu_line;  // [L] descending
+    const double *tau_t;    // [S][L]
+    const double *n_e;      // [S]
+    const double *prob_t;   // [S][T]
+    const int *line2level;  // [L]
+    const int *block_edge;  // [levels+1]
+    const int *ttype;       // [T]
+    const int *dest;        // [T]
+    const int *tline;       // [T]
+    // estimators (shell-major), n_est_copies private copies selected by XCC id
+    double *J, *nubar;      // [S]
+    double *jblue_t, *edot_t;  // [copies][S][L]
+    long long est_copy_stride; // S*L
+    int n_est_copies;
+    double *vhist;          // [G]
+    // config
+    int line_interaction_type, disable_line_scattering;
+    long long n_vpackets;
+    double survival_probability, tau_russian, spawn_start, spawn_end, sigma_thomson;
+    const double *grid;
+    int n_grid;
+    double grid0, grid_last, delta_nu;
+    // v-packet log (optional)
+    unsigned long long *vlog_count;
+    long long vlog_capacity;
+    long long *vlog_packet;
+    int *vlog_seq;
+    double *vlog_nu, *vlog_energy, *vlog_mu, *vlog_r;
+    // scratch / bookkeeping
+    uint32_t *rng_state;            // [n_slots][624]
+    unsigned long long *counters;   // [8]
+    long long *first_error;         // {packet index (min), code}
+    unsigned long long *next_packet;  // work counter for persistent scheduling
+    int debug_flags;                  // profiling experiments only: 1 = skip j_blue/Edotlu atomics, 2 = skip J/nu_bar
+};
+
+struct Packet {
+    double r, mu, nu, energy;
+    int next_line_id, shell, status;
+};
+
+// ---- MT19937, numpy legacy stream (np.random.seed / np.random.random; montecarlo_transport.py:65).
+// State lives in global scratch, one contiguous 2496-byte block per lane; values are produced incrementally
+// (one tempering + one in-place state update per 32-bit output), which is the same sequence as numpy's
+// block-wise regeneration.
+struct Rng {
+    uint32_t *mt;
+    int idx;
+    long long draws;
+
+    __device__ __forceinline__ void seed(uint32_t *state, uint32_t s)
+    {
+        mt = state;
+        uint32_t x = s;
+        mt[0] = x;
+        for (int i = 1; i < MT_N; ++i) {
+            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+            mt[i] = x;
+        }
+        idx = 0;
+        draws = 0;
+    }
+    __device__ __forceinline__ uint32_t next_u32()
+    {
+        int k = idx;
+        int k1 = (k + 1 == MT_N) ? 0 : k + 1;
+        int km = (k + 397 >= MT_N) ? k + 397 - MT_N : k + 397;
+        uint32_t y = (mt[k] & 0x80000000u) | (mt[k1] & 0x7fffffffu);
+        uint32_t v = mt[km] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        mt[k] = v;
+        idx = k1;
+        v ^= v >> 11;
+        v ^= (v << 7) & 0x9d2c5680u;
+        v ^= (v << 15) & 0xefc60000u;
+        v ^= v >> 18;
+        return v;
+    }
+    __device__ __forceinline__ double random()
+    {
+        uint32_t a = next_u32() >> 5, b = next_u32() >> 6;
+        ++draws;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+};
+
+// ---- frame transformations (tardis/transport/frame_transformations.py:12-109)
+template <bool FULL>
+__device__ __forceinline__ double doppler_factor(double velocity, double mu)
+{
+    const double inv_c = 1 / C_LIGHT;
+    double beta = velocity * inv_c;
+    if (!FULL) return 1.0 - mu * beta;
+    return (1.0 - mu * beta) / sqrt(1 - beta * beta);
+}
+template <bool FULL>
+__device__ __forceinline__ double inverse_doppler_factor(double velocity, double mu)
+{
+    const double inv_c = 1 / C_LIGHT;
+    double beta = velocity * inv_c;
+    if (!FULL) return 1.0 / (1.0 - mu * beta);
+    return (1.0 + mu * beta) / sqrt(1 - beta * beta);
+}
+__device__ __forceinline__ double aberration_cmf_to_lf(double r, double t, double mu)
+{
+    double ct = C_LIGHT * t;
+    double beta = r / ct;
+    return (mu + beta) / (1.0 + beta * mu);
+}
+__device__ __forceinline__ double aberration_lf_to_cmf(double r, double t, double mu)
+{
+    double ct = C_LIGHT * t;
+    double beta = r / ct;
+    return (mu - beta) / (1.0 - beta * mu);
+}
+
+// ---- distances (tardis/transport/geometry/calculate_distances.py:25-112,198-219)
+__device__ __forceinline__ void distance_boundary(double r, double mu, double r_inner, double r_outer, double &d,
+                                                  int &delta)
+{
+    if (mu > 0.0) {
+        d = sqrt(r_outer * r_outer + ((mu * mu - 1.0) * r * r)) - (r * mu);
+        delta = 1;
+    } else {
+        double check = r_inner * r_inner + (r * r * (mu * mu - 1.0));
+        if (check >= 0.0) {
+            d = -r * mu - sqrt(check);
+            delta = -1;
+        } else {
+            d = sqrt(r_outer * r_outer + ((mu * mu - 1.0) * r * r)) - (r * mu);
+            delta = 1;
+        }
+    }
+}
+__device__ __forceinline__ double distance_line_full_relativity(double nu_line, double nu, double t, double r, double mu)
+{
+    double nu_r = nu_line / nu;
+    double ct = C_LIGHT * t;
+    return -mu * r + (ct - nu_r * nu_r * sqrt(ct * ct - (1 + r * r * (1 - mu * mu) * (1 + 1.0 / (nu_r * nu_r))))) /
+                         (1 + nu_r * nu_r);
+}
+// returns false on the reference's MonteCarloException("nu difference is less than 0.0")
+template <bool FULL>
+__device__ __forceinline__ bool distance_line(double nu, double r, double mu, double comov_nu, bool is_last, double nu_line,
+                                              double t, double &d)
+{
+    if (is_last) { d = MISS_DISTANCE; return true; }
+    double nu_diff = comov_nu - nu_line;
+    double q = nu_diff / nu;
+    if (fabs(q) < CLOSE_LINE_THRESHOLD) { d = 0.0; return true; }
+    if (!(nu_diff >= 0)) return false;
+    if (FULL) d = distance_line_full_relativity(nu_line, nu, t, r, mu);
+    else d = q * C_LIGHT * t;
+    return true;
+}
+
+__device__ __forceinline__ void cross_shell(int &shell, int &status, int delta, int n_shells)
+{ // packets/movement.py:80-102
+    int next = shell + delta;
+    if (next >= n_shells) status = ST_EMITTED;
+    else if (next < 0) status = ST_REABSORBED;
+    else shell = next;
+}
+
+// fp64 hardware atomics (global_atomic_add_f64; compile with -munsafe-fp-atomics)
+__device__ __forceinline__ void atomic_add_f64(double *p, double v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace mc

@@ -1,0 +1,873 @@
+// tardis_mc_hip.hip -- host side of libtardis_mc_hip.so: the C ABI of include/tardis_mc.h over the HIP kernels.
+//
+// One context = one HIP device + one stream.  Inputs are copied to HBM and re-laid shell-major once
+// (tardis_mc_set_*), kernels run asynchronously on the context stream (tardis_mc_propagate), results are
+// re-laid to the reference's [L,S] layout on the device and copied out (tardis_mc_get_results).
+// RCCL is bound lazily with dlopen so that single-GPU users never map librccl.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/tardis_mc.h"
+#include "mc_device.hpp"
+#include "propagate_lane.hpp"
+#include "propagate_group.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes ? bytes : 16;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+// ---- RCCL, bound lazily
+struct Id128 { char bytes[TARDIS_MC_UNIQUE_ID_BYTES]; };
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /* ncclUniqueId by value: 128 bytes */ Id128, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+bool load_rccl(std::string &err)
+{
+    if (g_rccl.handle) return true;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) { err = std::string("dlopen(librccl.so) failed: ") + dlerror(); return false; }
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        err = "librccl.so lacks an expected nccl* symbol";
+        dlclose(h);
+        return false;
+    }
+    g_rccl.handle = h;
+    return true;
+}
+
+}  // namespace
+
+struct TardisMcContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    std::string err;
+    hipDeviceProp_t prop{};
+    // state flags
+    bool have_geometry = false, have_opacity = false, have_config = false, have_packets = false;
+    // geometry
+    int n_shells = 0;
+    double t_exp = 0;
+    DevBuf r_inner, r_outer;
+    // opacity
+    int n_lines = 0, n_trans = 0, n_levels = 0;
+    DevBuf nu_line, tau_t, n_e, prob_t, line2level, block_edge, ttype, dest, tline, staging;
+    // estimators: one allocation [J | nubar | vhist | pad | jblue copy0 | edot copy0 | jblue copy1.. | edot copy1..]
+    DevBuf est;
+    size_t est_S = 0, est_L = 0, est_G = 0;
+    int est_copies = 1;
+    bool est_valid = false;
+    // config
+    TardisMcConfig cfg{};
+    std::vector<double> grid_host;
+    DevBuf grid;
+    // packets
+    long long n_packets = 0;
+    DevBuf r0, mu0, nu0, e0, seeds, out_nu, out_e;
+    DevBuf li_f64[9], li_i64[5];
+    bool track = true;
+    // v-packet log
+    DevBuf vlog_count, vlog_packet, vlog_seq, vlog_nu, vlog_energy, vlog_mu, vlog_r;
+    long long vlog_capacity = 0;
+    // scratch
+    DevBuf rng_state, counters, first_error, next_packet, seeded_states;
+    long long chunk_packets = 8LL << 20;  // packets per seeded-state chunk (2496 B each) of the cooperative kernel
+    // launch geometry
+    int variant = 1;  // 0: lane-per-packet kernel; 1: cooperative 16-lanes-per-packet kernel (v-packets fall back to 0)
+    int blocks_per_cu = 8;
+    int debug_flags = 0;
+    // RCCL
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+namespace {
+
+int fail(TardisMcContext *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                      \
+    do {                                                                                                        \
+        hipError_t _e = (expr);                                                                                 \
+        if (_e != hipSuccess)                                                                                   \
+            return fail(ctx, TARDIS_MC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                        __LINE__);                                                                              \
+    } while (0)
+
+// [rows, cols] row-major -> [cols, rows] row-major (tile through LDS so both sides are coalesced)
+__global__ void transpose_kernel(const double *__restrict__ in, double *__restrict__ out, long long rows, long long cols)
+{
+    __shared__ double tile[32][33];
+    long long bx = (long long)blockIdx.x * 32, by = (long long)blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        long long r = by + j, c = bx + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = in[r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        long long c = bx + j, r = by + threadIdx.x;
+        if (r < rows && c < cols) out[c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+// sum private copies into copy 0 (in place)
+__global__ void reduce_copies_kernel(double *base, long long n, long long stride, int copies)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        double s = base[i];
+        for (int c = 1; c < copies; ++c) { s += base[i + c * stride]; base[i + c * stride] = 0.0; }
+        base[i] = s;
+    }
+}
+
+// diagnostics: element-wise device arithmetic for the numerics parity tests
+__global__ void debug_eval_kernel(int op, const double *x, const double *y, double *out, long long n, uint32_t *scratch)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (op == 7) {  // MT19937 stream of seed (uint32)x[0]
+        if (i == 0) {
+            mc::Rng rng;
+            rng.seed(scratch, (uint32_t)x[0]);
+            for (long long k = 0; k < n; ++k) out[k] = rng.random();
+        }
+        return;
+    }
+    if (i >= n) return;
+    double a = x[i], b = y ? y[i] : 0.0, r;
+    switch (op) {
+    case 0: r = a + b; break;
+    case 1: r = a * b; break;
+    case 2: r = a / b; break;
+    case 3: r = sqrt(a); break;
+    case 4: r = mcm::log(a); break;
+    case 5: r = mcm::exp(a); break;
+    case 6: r = a * b + a; break;  // must NOT be contracted into an fma
+    case 8: r = floor(a); break;
+    default: r = 0.0;
+    }
+    out[i] = r;
+}
+
+// ---- micro-benchmarks of the memory system (design input; not part of the product path)
+// which: 0 random fp64 atomic add, agent scope; 1 same, workgroup scope inside a per-XCD private slice;
+//        2 fp64 atomic add, 16 consecutive doubles per 16-lane group, agent scope; 3 same, workgroup scope/XCD slice;
+//        4 random 8-byte loads; 5 16-lane-coalesced 8-byte loads
+__global__ void microbench_kernel(int which, double *table, long long n, int iters, double *sink)
+{
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(gtid + 1);
+    const int lane16 = threadIdx.x & 15;
+    const bool xcd_slice = (which == 1 || which == 3);
+    long long span = n, base0 = 0;
+    if (xcd_slice) { span = n / 8; base0 = span * (mc::xcc_id() & 7); }
+    double acc = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        unsigned long long r = st >> 20;
+        long long idx;
+        if (which == 2 || which == 3 || which == 5) {
+            unsigned long long rg = __shfl(r, threadIdx.x & ~15, 64);  // group-uniform random base
+            idx = base0 + (long long)((rg % (unsigned long long)(span / 16)) * 16) + lane16;
+        } else
+            idx = base0 + (long long)(r % (unsigned long long)span);
+        if (which == 0 || which == 2) __hip_atomic_fetch_add(&table[idx], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (which == 1 || which == 3) __hip_atomic_fetch_add(&table[idx], 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else acc += table[idx];
+    }
+    if (acc == 123.456) sink[0] = acc;
+}
+
+hipError_t launch_transpose(hipStream_t s, const double *in, double *out, long long rows, long long cols)
+{
+    dim3 block(32, 8), grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, s, in, out, rows, cols);
+    return hipGetLastError();
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct EstLayout { size_t J, nubar, vhist, jblue, edot, copy_stride, reduce_elems, total; };
+EstLayout est_layout(size_t S, size_t L, size_t G, int copies)
+{
+    EstLayout e;
+    e.J = 0;
+    e.nubar = S;
+    e.vhist = 2 * S;
+    size_t head = align_up(2 * S + G, 32);
+    e.jblue = head;
+    e.edot = head + S * L;
+    e.copy_stride = 2 * S * L;             // distance between copy c and c+1 of the same table
+    e.reduce_elems = head + 2 * S * L;     // contiguous range that is all-reduced (copy 0)
+    e.total = head + (size_t)copies * 2 * S * L;
+    return e;
+}
+
+int ensure_estimators(TardisMcContext *ctx)
+{
+    if (!ctx->have_opacity || !ctx->have_config) return TARDIS_MC_OK;
+    size_t S = ctx->n_shells, L = ctx->n_lines, G = (size_t)ctx->cfg.n_spectrum_grid;
+    if (ctx->est_valid && ctx->est_S == S && ctx->est_L == L && ctx->est_G == G) return TARDIS_MC_OK;
+    EstLayout e = est_layout(S, L, G, ctx->est_copies);
+    HIP_TRY(ctx, ctx->est.ensure(e.total * sizeof(double)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->est.p, 0, e.total * sizeof(double), ctx->stream));
+    ctx->est_S = S; ctx->est_L = L; ctx->est_G = G;
+    ctx->est_valid = true;
+    return TARDIS_MC_OK;
+}
+
+template <typename T>
+int upload(TardisMcContext *ctx, DevBuf &buf, const T *host, size_t n)
+{
+    HIP_TRY(ctx, buf.ensure(n * sizeof(T)));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return TARDIS_MC_OK;
+}
+
+int upload_i32(TardisMcContext *ctx, DevBuf &buf, const int64_t *host, size_t n, std::vector<int> &tmp)
+{
+    tmp.resize(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (int)host[i];
+    int rc = upload(ctx, buf, tmp.data(), n);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // tmp is reused by the caller
+    return TARDIS_MC_OK;
+}
+
+mc::DeviceProblem make_device_problem(TardisMcContext *ctx)
+{
+    mc::DeviceProblem P{};
+    P.n_packets = ctx->n_packets;
+    P.r0 = ctx->r0.as<double>(); P.mu0 = ctx->mu0.as<double>(); P.nu0 = ctx->nu0.as<double>(); P.e0 = ctx->e0.as<double>();
+    P.seeds = ctx->seeds.as<uint32_t>();
+    P.out_nu = ctx->out_nu.as<double>(); P.out_e = ctx->out_e.as<double>();
+    if (ctx->track) {
+        double **f[] = {&P.li_radius, &P.li_nu, &P.li_energy, &P.li_before_nu, &P.li_before_mu, &P.li_before_energy,
+                        &P.li_after_nu, &P.li_after_mu, &P.li_after_energy};
+        for (int k = 0; k < 9; ++k) *f[k] = ctx->li_f64[k].as<double>();
+        long long **g[] = {&P.li_shell_id, &P.li_interaction_type, &P.li_line_absorb_id, &P.li_line_emit_id,
+                           &P.li_interactions_count};
+        for (int k = 0; k < 5; ++k) *g[k] = ctx->li_i64[k].as<long long>();
+    }
+    P.n_shells = ctx->n_shells;
+    P.r_inner = ctx->r_inner.as<double>(); P.r_outer = ctx->r_outer.as<double>();
+    P.t_exp = ctx->t_exp;
+    P.n_lines = ctx->n_lines; P.n_trans = ctx->n_trans;
+    P.nu_line = ctx->nu_line.as<double>(); P.tau_t = ctx->tau_t.as<double>(); P.n_e = ctx->n_e.as<double>();
+    P.prob_t = ctx->prob_t.as<double>();
+    P.line2level = ctx->line2level.as<int>(); P.block_edge = ctx->block_edge.as<int>(); P.ttype = ctx->ttype.as<int>();
+    P.dest = ctx->dest.as<int>(); P.tline = ctx->tline.as<int>();
+    EstLayout e = est_layout(ctx->est_S, ctx->est_L, ctx->est_G, ctx->est_copies);
+    double *base = ctx->est.as<double>();
+    P.J = base + e.J; P.nubar = base + e.nubar; P.vhist = base + e.vhist;
+    P.jblue_t = base + e.jblue; P.edot_t = base + e.edot;
+    P.est_copy_stride = (long long)e.copy_stride;
+    P.n_est_copies = ctx->est_copies;
+    const TardisMcConfig &c = ctx->cfg;
+    P.line_interaction_type = c.line_interaction_type;
+    P.disable_line_scattering = c.disable_line_scattering;
+    P.n_vpackets = c.number_of_vpackets;
+    P.survival_probability = c.survival_probability;
+    P.tau_russian = c.vpacket_tau_russian;
+    P.spawn_start = c.vpacket_spawn_start_frequency;
+    P.spawn_end = c.vpacket_spawn_end_frequency;
+    P.sigma_thomson = c.sigma_thomson;
+    P.grid = ctx->grid.as<double>();
+    P.n_grid = (int)c.n_spectrum_grid;
+    if (c.n_spectrum_grid >= 2) {
+        P.grid0 = ctx->grid_host[0];
+        P.grid_last = ctx->grid_host[c.n_spectrum_grid - 1];
+        P.delta_nu = ctx->grid_host[1] - ctx->grid_host[0];
+    }
+    if (c.enable_vpacket_tracking && c.number_of_vpackets > 0 && ctx->vlog_capacity > 0) {
+        P.vlog_count = ctx->vlog_count.as<unsigned long long>();
+        P.vlog_capacity = ctx->vlog_capacity;
+        P.vlog_packet = ctx->vlog_packet.as<long long>(); P.vlog_seq = ctx->vlog_seq.as<int>();
+        P.vlog_nu = ctx->vlog_nu.as<double>(); P.vlog_energy = ctx->vlog_energy.as<double>();
+        P.vlog_mu = ctx->vlog_mu.as<double>(); P.vlog_r = ctx->vlog_r.as<double>();
+    }
+    P.rng_state = ctx->rng_state.as<uint32_t>();
+    P.counters = ctx->counters.as<unsigned long long>();
+    P.first_error = ctx->first_error.as<long long>();
+    P.next_packet = ctx->next_packet.as<unsigned long long>();
+    P.debug_flags = ctx->debug_flags;
+    return P;
+}
+
+template <bool FULL, bool VPK>
+void launch_lane(TardisMcContext *ctx, const mc::DeviceProblem &P, int blocks, size_t lds)
+{
+    if (ctx->track)
+        hipLaunchKernelGGL((mc::propagate_lane_kernel<FULL, VPK, true>), dim3(blocks), dim3(256), lds, ctx->stream, P);
+    else
+        hipLaunchKernelGGL((mc::propagate_lane_kernel<FULL, VPK, false>), dim3(blocks), dim3(256), lds, ctx->stream, P);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tardis_mc_abi_version(void) { return TARDIS_MC_ABI_VERSION; }
+
+int tardis_mc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tardis_mc_create(int device_id, TardisMcContext **out_ctx)
+{
+    if (!out_ctx) return fail(nullptr, TARDIS_MC_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, TARDIS_MC_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, TARDIS_MC_ERR_INVALID_ARGUMENT, "device_id %d out of range [0,%d)", device_id, n);
+    TardisMcContext *ctx = new TardisMcContext();
+    ctx->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) {
+        int rc = fail(nullptr, TARDIS_MC_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    if (const char *v = getenv("TARDIS_MC_VARIANT")) ctx->variant = atoi(v);
+    if (const char *v = getenv("TARDIS_MC_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, atoi(v));
+    if (const char *v = getenv("TARDIS_MC_DEBUG_FLAGS")) ctx->debug_flags = atoi(v);
+    if (const char *v = getenv("TARDIS_MC_EST_COPIES")) ctx->est_copies = std::max(1, std::min(8, atoi(v)));
+    *out_ctx = ctx;
+    return TARDIS_MC_OK;
+}
+
+void tardis_mc_destroy(TardisMcContext *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    DevBuf *all[] = {&ctx->r_inner, &ctx->r_outer, &ctx->nu_line, &ctx->tau_t, &ctx->n_e, &ctx->prob_t, &ctx->line2level,
+                     &ctx->block_edge, &ctx->ttype, &ctx->dest, &ctx->tline, &ctx->staging, &ctx->est, &ctx->grid, &ctx->r0,
+                     &ctx->mu0, &ctx->nu0, &ctx->e0, &ctx->seeds, &ctx->out_nu, &ctx->out_e, &ctx->vlog_count,
+                     &ctx->vlog_packet, &ctx->vlog_seq, &ctx->vlog_nu, &ctx->vlog_energy, &ctx->vlog_mu, &ctx->vlog_r,
+                     &ctx->rng_state, &ctx->counters, &ctx->first_error, &ctx->next_packet, &ctx->seeded_states};
+    for (DevBuf *b : all) b->release();
+    for (auto &b : ctx->li_f64) b.release();
+    for (auto &b : ctx->li_i64) b.release();
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *tardis_mc_last_error(const TardisMcContext *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value)
+{
+    if (!ctx || !name) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    std::string n(name);
+    if (n == "variant") ctx->variant = (int)value;
+    else if (n == "blocks_per_cu") ctx->blocks_per_cu = std::max(1, (int)value);
+    else if (n == "track_last_interaction") ctx->track = value != 0;
+    else if (n == "estimator_copies") { ctx->est_copies = std::max(1, std::min(8, (int)value)); ctx->est_valid = false; }
+    else if (n == "vpacket_log_capacity") ctx->vlog_capacity = value;
+    else if (n == "debug_flags") ctx->debug_flags = (int)value;
+    else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
+    else return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_set_geometry(TardisMcContext *ctx, const TardisMcGeometry *g)
+{
+    if (!ctx || !g || g->n_shells <= 0 || !g->r_inner || !g->r_outer)
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "invalid geometry");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->r_inner, g->r_inner, (size_t)g->n_shells))) return rc;
+    if ((rc = upload(ctx, ctx->r_outer, g->r_outer, (size_t)g->n_shells))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_shells = (int)g->n_shells;
+    ctx->t_exp = g->time_explosion;
+    ctx->have_geometry = true;
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
+{
+    if (!ctx || !o || o->n_lines <= 0 || o->n_shells <= 0 || o->n_transitions <= 0 || !o->electron_density ||
+        !o->line_list_nu || !o->tau_sobolev || !o->transition_probabilities)
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "invalid opacity state");
+    if (o->n_lines > 0x7ffffff0LL || o->n_transitions > 0x7ffffff0LL)
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "line / transition count exceeds 32-bit device indices");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t L = (size_t)o->n_lines, S = (size_t)o->n_shells, T = (size_t)o->n_transitions;
+    const size_t E = (size_t)o->n_macro_block_edges;
+    // validate the macro-atom index tables on the host: the device walks them without bounds checks
+    const bool macro = T > 1 || E > 1;
+    if (macro) {
+        if (!o->line2macro_level_upper || !o->macro_block_edge_index || !o->transition_type || !o->destination_level_id ||
+            !o->transition_line_id || E < 2)
+            return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "macro-atom tables missing");
+        const long long n_levels = (long long)E - 1;
+        for (size_t i = 0; i + 1 < E; ++i)
+            if (o->macro_block_edge_index[i] < 0 || o->macro_block_edge_index[i] > o->macro_block_edge_index[i + 1] ||
+                o->macro_block_edge_index[i + 1] > (long long)T)
+                return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "macro_block_edge_index not monotone within [0,T]");
+        for (size_t i = 0; i < L; ++i)
+            if (o->line2macro_level_upper[i] < 0 || o->line2macro_level_upper[i] >= n_levels)
+                return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "line2macro_level_upper[%zu] out of range", i);
+        for (size_t i = 0; i < T; ++i) {
+            if (o->transition_type[i] >= 0 && (o->destination_level_id[i] < 0 || o->destination_level_id[i] >= n_levels))
+                return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "destination_level_id[%zu] out of range", i);
+            if (o->transition_type[i] == -1 && (o->transition_line_id[i] < 0 || o->transition_line_id[i] >= (long long)L))
+                return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "transition_line_id[%zu] out of range", i);
+        }
+    }
+    int rc;
+    if ((rc = upload(ctx, ctx->nu_line, o->line_list_nu, L))) return rc;
+    if ((rc = upload(ctx, ctx->n_e, o->electron_density, S))) return rc;
+    // tau [L,S] -> [S][L]
+    HIP_TRY(ctx, ctx->staging.ensure(std::max(L, T) * S * sizeof(double)));
+    HIP_TRY(ctx, ctx->tau_t.ensure(L * S * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->staging.p, o->tau_sobolev, L * S * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->staging.as<double>(), ctx->tau_t.as<double>(), (long long)L, (long long)S));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // probabilities [T,S] -> [S][T]
+    HIP_TRY(ctx, ctx->prob_t.ensure(T * S * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->staging.p, o->transition_probabilities, T * S * sizeof(double), hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->staging.as<double>(), ctx->prob_t.as<double>(), (long long)T, (long long)S));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> tmp;
+    static const int64_t zero64 = 0;
+    if ((rc = upload_i32(ctx, ctx->line2level, macro ? o->line2macro_level_upper : &zero64, macro ? L : 1, tmp))) return rc;
+    if ((rc = upload_i32(ctx, ctx->block_edge, macro ? o->macro_block_edge_index : &zero64, macro ? E : 1, tmp))) return rc;
+    if ((rc = upload_i32(ctx, ctx->ttype, macro ? o->transition_type : &zero64, macro ? T : 1, tmp))) return rc;
+    if ((rc = upload_i32(ctx, ctx->dest, macro ? o->destination_level_id : &zero64, macro ? T : 1, tmp))) return rc;
+    if ((rc = upload_i32(ctx, ctx->tline, macro ? o->transition_line_id : &zero64, macro ? T : 1, tmp))) return rc;
+    if (ctx->have_geometry && (int)S != ctx->n_shells)
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "opacity has %zu shells, geometry has %d", S, ctx->n_shells);
+    ctx->n_lines = (int)L; ctx->n_trans = (int)T; ctx->n_levels = macro ? (int)E - 1 : 0;
+    if (!ctx->have_geometry) ctx->n_shells = (int)S;
+    ctx->have_opacity = true;
+    return ensure_estimators(ctx);
+}
+
+int tardis_mc_set_config(TardisMcContext *ctx, const TardisMcConfig *c)
+{
+    if (!ctx || !c) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "invalid config");
+    if (c->n_spectrum_grid < 0 || (c->n_spectrum_grid > 0 && !c->spectrum_frequency_grid))
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "spectrum_frequency_grid missing");
+    if (c->number_of_vpackets > 0 && c->n_spectrum_grid < 2)
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "v-packets need a spectrum grid with >= 2 edges");
+    if (c->line_interaction_type < 0 || c->line_interaction_type > 2)
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "line_interaction_type must be 0, 1 or 2");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->cfg = *c;
+    ctx->grid_host.assign(c->spectrum_frequency_grid, c->spectrum_frequency_grid + c->n_spectrum_grid);
+    ctx->cfg.spectrum_frequency_grid = ctx->grid_host.data();
+    int rc;
+    if ((rc = upload(ctx, ctx->grid, ctx->grid_host.data(), ctx->grid_host.size()))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_config = true;
+    return ensure_estimators(ctx);
+}
+
+int tardis_mc_set_packets(TardisMcContext *ctx, const TardisMcPackets *p)
+{
+    if (!ctx || !p || p->n_packets < 0 ||
+        (p->n_packets > 0 && (!p->initial_radii || !p->initial_nus || !p->initial_mus || !p->initial_energies || !p->packet_seeds)))
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "invalid packets");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)p->n_packets;
+    int rc;
+    if ((rc = upload(ctx, ctx->r0, p->initial_radii, P))) return rc;
+    if ((rc = upload(ctx, ctx->mu0, p->initial_mus, P))) return rc;
+    if ((rc = upload(ctx, ctx->nu0, p->initial_nus, P))) return rc;
+    if ((rc = upload(ctx, ctx->e0, p->initial_energies, P))) return rc;
+    std::vector<uint32_t> seeds(P);
+    for (size_t i = 0; i < P; ++i) seeds[i] = (uint32_t)p->packet_seeds[i];  // np.random.seed(int) -> init_genrand(uint32)
+    if ((rc = upload(ctx, ctx->seeds, seeds.data(), P))) return rc;
+    HIP_TRY(ctx, ctx->out_nu.ensure(P * sizeof(double)));
+    HIP_TRY(ctx, ctx->out_e.ensure(P * sizeof(double)));
+    if (ctx->track) {
+        for (auto &b : ctx->li_f64) HIP_TRY(ctx, b.ensure(P * sizeof(double)));
+        for (auto &b : ctx->li_i64) HIP_TRY(ctx, b.ensure(P * sizeof(long long)));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_packets = (long long)P;
+    ctx->have_packets = true;
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_reset_estimators(TardisMcContext *ctx)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_estimators(ctx);
+    if (rc) return rc;
+    if (!ctx->est_valid) return fail(ctx, TARDIS_MC_ERR_STATE, "set_opacity and set_config must precede reset_estimators");
+    EstLayout e = est_layout(ctx->est_S, ctx->est_L, ctx->est_G, ctx->est_copies);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->est.p, 0, e.total * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, ctx->counters.ensure(TARDIS_MC_N_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, TARDIS_MC_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_propagate(TardisMcContext *ctx)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_geometry || !ctx->have_opacity || !ctx->have_config || !ctx->have_packets)
+        return fail(ctx, TARDIS_MC_ERR_STATE, "set_geometry/set_opacity/set_config/set_packets must precede propagate");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_estimators(ctx);
+    if (rc) return rc;
+    if (!ctx->counters.p) {
+        HIP_TRY(ctx, ctx->counters.ensure(TARDIS_MC_N_COUNTERS * sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, TARDIS_MC_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
+    }
+    const TardisMcConfig &c = ctx->cfg;
+    const bool vpk = c.number_of_vpackets > 0;
+    // v-packet log buffers
+    if (c.enable_vpacket_tracking && vpk) {
+        if (ctx->vlog_capacity <= 0) ctx->vlog_capacity = std::max<long long>(1024, ctx->n_packets * c.number_of_vpackets * 64);
+        size_t cap = (size_t)ctx->vlog_capacity;
+        HIP_TRY(ctx, ctx->vlog_count.ensure(sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->vlog_count.p, 0, sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, ctx->vlog_packet.ensure(cap * sizeof(long long)));
+        HIP_TRY(ctx, ctx->vlog_seq.ensure(cap * sizeof(int)));
+        HIP_TRY(ctx, ctx->vlog_nu.ensure(cap * sizeof(double)));
+        HIP_TRY(ctx, ctx->vlog_energy.ensure(cap * sizeof(double)));
+        HIP_TRY(ctx, ctx->vlog_mu.ensure(cap * sizeof(double)));
+        HIP_TRY(ctx, ctx->vlog_r.ensure(cap * sizeof(double)));
+    }
+    const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    HIP_TRY(ctx, ctx->first_error.ensure(2 * sizeof(long long)));
+    const long long init_err[2] = {0x7fffffffffffffffLL, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->first_error.p, init_err, sizeof init_err, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, ctx->next_packet.ensure(sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // init_err lives on this stack frame
+    const bool cooperative = ctx->variant == 1 && !vpk;
+
+    if (!cooperative) {
+        // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment
+        long long want_blocks = (ctx->n_packets + 255) / 256;
+        int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)cus * ctx->blocks_per_cu));
+        HIP_TRY(ctx, ctx->rng_state.ensure((size_t)blocks * 256 * mc::MT_N * sizeof(uint32_t)));
+        mc::DeviceProblem P = make_device_problem(ctx);
+        const size_t lds = 2 * (size_t)ctx->n_shells * sizeof(double);
+        if (lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        if (ctx->n_packets > 0) {
+            if (c.enable_full_relativity) { if (vpk) launch_lane<true, true>(ctx, P, blocks, lds); else launch_lane<true, false>(ctx, P, blocks, lds); }
+            else { if (vpk) launch_lane<false, true>(ctx, P, blocks, lds); else launch_lane<false, false>(ctx, P, blocks, lds); }
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    } else {
+        // variant 1: cooperative kernel; MT19937 states are seeded per chunk by a lane-per-packet kernel
+        const long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
+        HIP_TRY(ctx, ctx->seeded_states.ensure((size_t)chunk * mc::MT_N * sizeof(uint32_t)));
+        mc::DeviceProblem P = make_device_problem(ctx);
+        const size_t lds = (size_t)mc::GROUPS_PER_BLOCK * mc::MT_N * 4 + 2 * (size_t)ctx->n_shells * sizeof(double);
+        if (lds > 160 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
+        const int blocks_per_cu = std::max(1, std::min(ctx->blocks_per_cu, (int)((160 * 1024) / lds)));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        for (long long first = 0; first < ctx->n_packets; first += chunk) {
+            const long long count = std::min(chunk, ctx->n_packets - first);
+            hipLaunchKernelGGL(mc::seed_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->seeds.as<uint32_t>(), ctx->seeded_states.as<uint32_t>(), first, count);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), ctx->stream));
+            long long want_blocks = (count + mc::GROUPS_PER_BLOCK - 1) / mc::GROUPS_PER_BLOCK;
+            int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)cus * blocks_per_cu));
+            auto k = c.enable_full_relativity
+                         ? (ctx->track ? mc::propagate_group_kernel<true, true> : mc::propagate_group_kernel<true, false>)
+                         : (ctx->track ? mc::propagate_group_kernel<false, true> : mc::propagate_group_kernel<false, false>);
+            hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, ctx->stream, P, ctx->seeded_states.as<uint32_t>(), first, count);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = true;
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_synchronize(TardisMcContext *ctx)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_last_propagate_ms(TardisMcContext *ctx, double *out_ms)
+{
+    if (!ctx || !out_ms) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->timed) return fail(ctx, TARDIS_MC_ERR_STATE, "no propagate has been timed yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    *out_ms = (double)ms;
+    return TARDIS_MC_OK;
+}
+
+static int reduce_estimator_copies(TardisMcContext *ctx)
+{
+    if (ctx->est_copies <= 1) return TARDIS_MC_OK;
+    EstLayout e = est_layout(ctx->est_S, ctx->est_L, ctx->est_G, ctx->est_copies);
+    long long n = (long long)(2 * ctx->est_S * ctx->est_L);
+    hipLaunchKernelGGL(reduce_copies_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->est.as<double>() + e.jblue, n,
+                       (long long)e.copy_stride, ctx->est_copies);
+    HIP_TRY(ctx, hipGetLastError());
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *res)
+{
+    if (!ctx || !res) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->est_valid) return fail(ctx, TARDIS_MC_ERR_STATE, "nothing to fetch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = reduce_estimator_copies(ctx);
+    if (rc) return rc;
+    const size_t P = (size_t)ctx->n_packets, S = ctx->est_S, L = ctx->est_L, G = ctx->est_G;
+    EstLayout e = est_layout(S, L, G, ctx->est_copies);
+    double *base = ctx->est.as<double>();
+    auto d2h = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        if (!dst || !bytes) return hipSuccess;
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    };
+    if (ctx->have_packets) {
+        HIP_TRY(ctx, d2h(res->output_nus, ctx->out_nu.p, P * 8));
+        HIP_TRY(ctx, d2h(res->output_energies, ctx->out_e.p, P * 8));
+        if (ctx->track) {
+            double *f[] = {res->li_radius, res->li_nu, res->li_energy, res->li_before_nu, res->li_before_mu,
+                           res->li_before_energy, res->li_after_nu, res->li_after_mu, res->li_after_energy};
+            for (int k = 0; k < 9; ++k) HIP_TRY(ctx, d2h(f[k], ctx->li_f64[k].p, P * 8));
+            int64_t *g[] = {res->li_shell_id, res->li_interaction_type, res->li_line_absorb_id, res->li_line_emit_id,
+                            res->li_interactions_count};
+            for (int k = 0; k < 5; ++k) HIP_TRY(ctx, d2h(g[k], ctx->li_i64[k].p, P * 8));
+        }
+    }
+    HIP_TRY(ctx, d2h(res->j_estimator, base + e.J, S * 8));
+    HIP_TRY(ctx, d2h(res->nu_bar_estimator, base + e.nubar, S * 8));
+    HIP_TRY(ctx, d2h(res->v_packets_energy_hist, base + e.vhist, G * 8));
+    if (res->j_blue_estimator || res->edotlu_estimator) {
+        HIP_TRY(ctx, ctx->staging.ensure(L * S * sizeof(double)));
+        if (res->j_blue_estimator) {
+            HIP_TRY(ctx, launch_transpose(ctx->stream, base + e.jblue, ctx->staging.as<double>(), (long long)S, (long long)L));
+            HIP_TRY(ctx, d2h(res->j_blue_estimator, ctx->staging.p, L * S * 8));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        if (res->edotlu_estimator) {
+            HIP_TRY(ctx, launch_transpose(ctx->stream, base + e.edot, ctx->staging.as<double>(), (long long)S, (long long)L));
+            HIP_TRY(ctx, d2h(res->edotlu_estimator, ctx->staging.p, L * S * 8));
+        }
+    }
+    unsigned long long cnt[TARDIS_MC_N_COUNTERS] = {0};
+    if (ctx->counters.p) HIP_TRY(ctx, d2h(cnt, ctx->counters.p, sizeof cnt));
+    long long ferr[2] = {0x7fffffffffffffffLL, 0};
+    if (ctx->first_error.p) HIP_TRY(ctx, d2h(ferr, ctx->first_error.p, sizeof ferr));
+    unsigned long long vcount = 0;
+    const bool vlog = ctx->cfg.enable_vpacket_tracking && ctx->cfg.number_of_vpackets > 0 && ctx->vlog_count.p;
+    if (vlog) HIP_TRY(ctx, d2h(&vcount, ctx->vlog_count.p, sizeof vcount));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < TARDIS_MC_N_COUNTERS; ++k) res->counters[k] = (int64_t)cnt[k];
+    res->counters[TARDIS_MC_CNT_PACKETS] = ctx->n_packets;
+    res->first_error_packet = -1;
+    res->error_code = 0;
+    if (ferr[0] != 0x7fffffffffffffffLL) {
+        res->first_error_packet = ferr[0];
+        double marker = 0.0;  // the failing lane stored its error code in out_nu[packet]
+        HIP_TRY(ctx, hipMemcpy(&marker, ctx->out_nu.as<double>() + ferr[0], 8, hipMemcpyDeviceToHost));
+        res->error_code = (int)marker;
+    }
+    res->vpacket_log_count = 0;
+    if (vlog) {
+        res->vpacket_log_count = (int64_t)vcount;
+        size_t n = (size_t)std::min<unsigned long long>(vcount, (unsigned long long)ctx->vlog_capacity);
+        std::vector<long long> pk(n);
+        std::vector<int> seq(n);
+        std::vector<double> nu(n), en(n), mu(n), rr(n);
+        if (n) {
+            HIP_TRY(ctx, hipMemcpy(pk.data(), ctx->vlog_packet.p, n * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(seq.data(), ctx->vlog_seq.p, n * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(nu.data(), ctx->vlog_nu.p, n * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(en.data(), ctx->vlog_energy.p, n * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(mu.data(), ctx->vlog_mu.p, n * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(rr.data(), ctx->vlog_r.p, n * 8, hipMemcpyDeviceToHost));
+        }
+        // the reference consolidates per-packet lists in packet order (packet_collections.py:310-396)
+        std::vector<size_t> order(n);
+        std::iota(order.begin(), order.end(), (size_t)0);
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return pk[a] != pk[b] ? pk[a] < pk[b] : seq[a] < seq[b]; });
+        size_t m = std::min<size_t>(n, (size_t)std::max<int64_t>(0, res->vpacket_log_capacity));
+        for (size_t k = 0; k < m; ++k) {
+            size_t s = order[k];
+            if (res->vpacket_nus) res->vpacket_nus[k] = nu[s];
+            if (res->vpacket_energies) res->vpacket_energies[k] = en[s];
+            if (res->vpacket_initial_mus) res->vpacket_initial_mus[k] = mu[s];
+            if (res->vpacket_initial_rs) res->vpacket_initial_rs[k] = rr[s];
+        }
+    }
+    return res->error_code;
+}
+
+int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const TardisMcGeometry *geometry,
+                  const TardisMcOpacity *opacity, const TardisMcConfig *config, TardisMcResult *result)
+{
+    int rc;
+    if ((rc = tardis_mc_set_geometry(ctx, geometry))) return rc;
+    if ((rc = tardis_mc_set_opacity(ctx, opacity))) return rc;
+    if ((rc = tardis_mc_set_config(ctx, config))) return rc;
+    if (result && result->vpacket_log_capacity > 0) ctx->vlog_capacity = result->vpacket_log_capacity;
+    if ((rc = tardis_mc_set_packets(ctx, packets))) return rc;
+    if ((rc = tardis_mc_reset_estimators(ctx))) return rc;
+    if ((rc = tardis_mc_propagate(ctx))) return rc;
+    if ((rc = tardis_mc_synchronize(ctx))) return rc;
+    return tardis_mc_get_results(ctx, result);
+}
+
+/* ---- multi-GPU -------------------------------------------------------------------------------------- */
+int tardis_mc_comm_get_unique_id(uint8_t out_id[TARDIS_MC_UNIQUE_ID_BYTES])
+{
+    std::string err;
+    if (!out_id) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!load_rccl(err)) return fail(nullptr, TARDIS_MC_ERR_COMM, "%s", err.c_str());
+    Id128 id;
+    memset(&id, 0, sizeof id);
+    int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) return fail(nullptr, TARDIS_MC_ERR_COMM, "ncclGetUniqueId failed (%d)", r);
+    memcpy(out_id, id.bytes, TARDIS_MC_UNIQUE_ID_BYTES);
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_comm_init(TardisMcContext *ctx, int rank, int world_size, const uint8_t id[TARDIS_MC_UNIQUE_ID_BYTES])
+{
+    if (!ctx || !id || world_size < 1 || rank < 0 || rank >= world_size)
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "invalid communicator arguments");
+    std::string err;
+    if (!load_rccl(err)) return fail(ctx, TARDIS_MC_ERR_COMM, "%s", err.c_str());
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Id128 uid;
+    memcpy(uid.bytes, id, TARDIS_MC_UNIQUE_ID_BYTES);
+    int r = g_rccl.CommInitRank(&ctx->comm, world_size, uid, rank);
+    if (r != 0) return fail(ctx, TARDIS_MC_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    ctx->rank = rank;
+    ctx->world = world_size;
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_allreduce_estimators(TardisMcContext *ctx)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->est_valid) return fail(ctx, TARDIS_MC_ERR_STATE, "no estimators allocated");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = reduce_estimator_copies(ctx);
+    if (rc) return rc;
+    if (ctx->world <= 1) return TARDIS_MC_OK;
+    if (!ctx->comm) return fail(ctx, TARDIS_MC_ERR_STATE, "tardis_mc_comm_init has not been called");
+    EstLayout e = est_layout(ctx->est_S, ctx->est_L, ctx->est_G, ctx->est_copies);
+    // ncclDouble = 8, ncclSum = 0; one in-place all-reduce over [J | nu_bar | v-hist | j_blue | Edotlu]
+    int r = g_rccl.AllReduce(ctx->est.p, ctx->est.p, e.reduce_elems, 8, 0, ctx->comm, ctx->stream);
+    if (r != 0) return fail(ctx, TARDIS_MC_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return TARDIS_MC_OK;
+}
+
+/* ---- diagnostics (numerics parity tests) ------------------------------------------------------------- */
+int tardis_mc_debug_eval(TardisMcContext *ctx, int op, const double *x, const double *y, double *out, int64_t n)
+{
+    if (!ctx || !x || !out || n <= 0) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dx, dy, dout, scratch;
+    size_t nx = (op == 7) ? 1 : (size_t)n;
+    HIP_TRY(ctx, dx.ensure(nx * 8));
+    HIP_TRY(ctx, dout.ensure((size_t)n * 8));
+    HIP_TRY(ctx, scratch.ensure(mc::MT_N * 4));
+    HIP_TRY(ctx, hipMemcpy(dx.p, x, nx * 8, hipMemcpyHostToDevice));
+    if (y) { HIP_TRY(ctx, dy.ensure((size_t)n * 8)); HIP_TRY(ctx, hipMemcpy(dy.p, y, (size_t)n * 8, hipMemcpyHostToDevice)); }
+    int blocks = op == 7 ? 1 : (int)((n + 255) / 256);
+    hipLaunchKernelGGL(debug_eval_kernel, dim3(blocks), dim3(op == 7 ? 64 : 256), 0, ctx->stream, op, dx.as<double>(),
+                       y ? dy.as<double>() : nullptr, dout.as<double>(), (long long)n, scratch.as<uint32_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    dx.release(); dy.release(); dout.release(); scratch.release();
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_debug_microbench(TardisMcContext *ctx, int which, int64_t n_doubles, int iters, int blocks, double *out_ms)
+{
+    if (!ctx || !out_ms || n_doubles < 1024 || iters < 1 || blocks < 1) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf table, sink;
+    HIP_TRY(ctx, table.ensure((size_t)n_doubles * 8));
+    HIP_TRY(ctx, sink.ensure(8));
+    HIP_TRY(ctx, hipMemsetAsync(table.p, 0, (size_t)n_doubles * 8, ctx->stream));
+    for (int rep = 0; rep < 2; ++rep) {  // first launch warms up
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        hipLaunchKernelGGL(microbench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, which, table.as<double>(),
+                           (long long)n_doubles, iters, sink.as<double>());
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    }
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    *out_ms = ms;
+    table.release(); sink.release();
+    return TARDIS_MC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+"""Thin object wrapper over the C ABI (one Engine = one TardisMcContext = one GPU + one stream)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi, _lib
+from . import state as st
+
+
+class MonteCarloException(ValueError):
+    """Mirror of tardis.transport.montecarlo.utils.MonteCarloException (utils.py:9)."""
+
+
+class MacroAtomError(ValueError):
+    """Mirror of tardis.transport.montecarlo.macro_atom.MacroAtomError (macro_atom.py:15)."""
+
+
+class Engine:
+    def __init__(self, device_id: int = 0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.tardis_mc_create(int(device_id), C.byref(h))
+        if rc != 0:
+            msg = self._L.tardis_mc_last_error(None).decode()
+            raise _lib.EngineUnavailable(f"tardis_mc_create(device {device_id}) failed ({rc}): {msg}")
+        self._h = h
+        self._keep = {}
+        self.n_packets = self.n_shells = self.n_lines = self.n_grid = 0
+        self._vpk_log = False
+        self._n_v = 0
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tardis_mc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what, packet_index=-1):
+        if rc == 0:
+            return
+        msg = self._L.tardis_mc_last_error(self._h).decode()
+        exc = None
+        if rc == _abi.ERR_MONTECARLO:
+            exc = MonteCarloException("nu difference is less than 0.0")
+        elif rc == _abi.ERR_MACRO_ATOM:
+            exc = MacroAtomError("MacroAtom ran out of the block. This should not happen as the sum of "
+                                 "probabilities is normalized to 1 and the probability_event should be less than 1")
+        elif rc == _abi.ERR_UNSUPPORTED:
+            exc = NotImplementedError("macro-atom transition type outside classic mode (continuum processes)")
+        if exc is not None:
+            exc.packet_index = packet_index  # lowest failing packet index (the reference aborts on the first one)
+            raise exc
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+    # -- staged API
+    def set_option(self, name: str, value: int):
+        self._check(self._L.tardis_mc_set_option(self._h, name.encode(), int(value)), f"set_option({name})")
+
+    def set_geometry(self, geometry, time_explosion=None):
+        m = _abi.marshal_geometry(geometry, time_explosion)
+        self._check(self._L.tardis_mc_set_geometry(self._h, m.ref()), "set_geometry")
+        self.n_shells = int(m.struct.n_shells)
+
+    def set_opacity(self, opacity_state):
+        m = _abi.marshal_opacity(opacity_state)
+        self._check(self._L.tardis_mc_set_opacity(self._h, m.ref()), "set_opacity")
+        self.n_lines, self.n_shells = int(m.struct.n_lines), int(m.struct.n_shells)
+
+    def set_config(self, montecarlo_configuration, spectrum_frequency_grid, number_of_vpackets=None, sigma_thomson=None):
+        m = _abi.marshal_config(montecarlo_configuration, spectrum_frequency_grid, number_of_vpackets, sigma_thomson)
+        self._check(self._L.tardis_mc_set_config(self._h, m.ref()), "set_config")
+        self.n_grid = int(m.struct.n_spectrum_grid)
+        self._n_v = int(m.struct.number_of_vpackets)
+        self._vpk_log = bool(m.struct.enable_vpacket_tracking) and self._n_v > 0
+
+    def set_packets(self, packet_collection):
+        m = _abi.marshal_packets(packet_collection)
+        self._check(self._L.tardis_mc_set_packets(self._h, m.ref()), "set_packets")
+        self.n_packets = int(m.struct.n_packets)
+
+    def reset_estimators(self):
+        self._check(self._L.tardis_mc_reset_estimators(self._h), "reset_estimators")
+
+    def propagate(self):
+        self._check(self._L.tardis_mc_propagate(self._h), "propagate")
+
+    def synchronize(self):
+        self._check(self._L.tardis_mc_synchronize(self._h), "synchronize")
+
+    def last_propagate_ms(self) -> float:
+        v = C.c_double()
+        self._check(self._L.tardis_mc_last_propagate_ms(self._h, C.byref(v)), "last_propagate_ms")
+        return v.value
+
+    def get_results(self, output_nus=None, output_energies=None, track_last_interaction=True,
+                    want_line_estimators=True, vpacket_log_capacity=None) -> _abi.ResultBuffers:
+        trackers = st.LastInteractionTrackers(self.n_packets) if track_last_interaction else None
+        cap = 0
+        if self._vpk_log:
+            cap = int(vpacket_log_capacity if vpacket_log_capacity is not None else self.n_packets * self._n_v * 64)
+        res = _abi.ResultBuffers(self.n_packets, self.n_shells, self.n_lines, self.n_grid, output_nus, output_energies,
+                                 trackers, cap, want_line_estimators)
+        rc = self._L.tardis_mc_get_results(self._h, res.ref())
+        self._check(rc, "get_results", int(res.struct.first_error_packet))
+        return res
+
+    # -- multi-GPU
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * _abi.UNIQUE_ID_BYTES)()
+        rc = _lib.lib().tardis_mc_comm_get_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"tardis_mc_comm_get_unique_id failed ({rc})")
+        return bytes(buf)
+
+    def comm_init(self, rank: int, world_size: int, unique_id: bytes):
+        buf = (C.c_uint8 * _abi.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._L.tardis_mc_comm_init(self._h, rank, world_size, buf), "comm_init")
+
+    def allreduce_estimators(self):
+        self._check(self._L.tardis_mc_allreduce_estimators(self._h), "allreduce_estimators")
+
+    # -- diagnostics
+    def debug_eval(self, op: int, x, y=None, n=None) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = int(x.size if n is None else n)
+        out = np.empty(n)
+        yp = None
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float64)
+            yp = y.ctypes.data
+        self._check(self._L.tardis_mc_debug_eval(self._h, op, x.ctypes.data, yp, out.ctypes.data, n), "debug_eval")
+        return out
+
+
+    def debug_microbench(self, which: int, n_doubles: int, iters: int, blocks: int) -> float:
+        v = C.c_double()
+        self._check(self._L.tardis_mc_debug_microbench(self._h, which, n_doubles, iters, blocks, C.byref(v)), "microbench")
+        return v.value
+
+
+def device_count() -> int:
+    return int(_lib.lib().tardis_mc_device_count())

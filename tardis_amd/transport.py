@@ -1,0 +1,203 @@
+"""Drop-in replacement of the reference's Monte Carlo main loop, backed by the HIP engine.
+
+``montecarlo_transport_with_vpackets`` has the signature and return tuple of the reference function
+(tardis/transport/montecarlo/modes/montecarlo_transport.py:238-373), so a TARDIS installation switches
+engines with one assignment in ``modes/classic/solver.py``.  It accepts the reference's
+own jitclass objects or the containers of ``tardis_amd.state`` (duck typing on attribute names).
+
+``MCTransportSolverHIP`` mirrors ``MCTransportSolverClassic.run / run_classic``
+(tardis/transport/montecarlo/modes/classic/solver.py:154-273) and ``MonteCarloTransportState`` the result
+properties the rest of TARDIS reads (montecarlo_transport_state.py:106-160).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import state as st
+from .engine import Engine, MacroAtomError, MonteCarloException  # noqa: F401  (re-exported)
+
+_engines: dict[int, Engine] = {}
+
+
+def get_engine(device_id: int | None = None) -> Engine:
+    """Process-wide engine per device (one process per GPU: LOCAL_RANK selects the device)."""
+    if device_id is None:
+        device_id = int(os.environ.get("LOCAL_RANK", "0"))
+    eng = _engines.get(device_id)
+    if eng is None:
+        eng = _engines[device_id] = Engine(device_id)
+    return eng
+
+
+def _fill_trackers(trackers, soa: st.LastInteractionTrackers):
+    """Accept the reference's list of per-packet TrackerLastInteraction objects and fill them in place."""
+    if trackers is None or isinstance(trackers, st.LastInteractionTrackers):
+        return
+    names = st.LastInteractionTrackers.F64_FIELDS + st.LastInteractionTrackers.I64_FIELDS
+    cols = {n: getattr(soa, n) for n in names}
+    for i, t in enumerate(trackers):
+        for n in names:
+            setattr(t, n, cols[n][i].item())
+
+
+def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, time_explosion: float,
+                                       opacity_state_numba, montecarlo_configuration, spectrum_frequency_grid,
+                                       trackers, number_of_vpackets: int, show_progress_bars: bool = False,
+                                       packet_propagation_function=None, *, engine: Engine | None = None):
+    """Run the classic (line + electron scattering) Monte Carlo transport on the GPU.
+
+    Returns ``(v_packets_energy_hist, vpacket_tracker, estimators_bulk, estimators_line)`` and mutates
+    ``packet_collection.output_nus / output_energies`` and ``trackers`` in place, exactly like the reference.
+    ``packet_propagation_function`` is accepted for signature compatibility; only the classic homologous mode
+    is implemented by the engine (anything else must stay on the reference path).
+    """
+    if packet_propagation_function is not None:
+        name = getattr(packet_propagation_function, "__name__", "")
+        mod = getattr(packet_propagation_function, "__module__", "") or ""
+        if name != "packet_propagation" or "nonhomologous" in mod or "iip" in mod:
+            raise NotImplementedError("the HIP engine implements the classic homologous packet_propagation only")
+    eng = engine or get_engine()
+    eng.set_geometry(geometry_state_numba, time_explosion)
+    eng.set_opacity(opacity_state_numba)
+    eng.set_config(montecarlo_configuration, spectrum_frequency_grid, number_of_vpackets)
+    track = trackers is not None
+    eng.set_option("track_last_interaction", int(track))
+    eng.set_packets(packet_collection)
+    eng.reset_estimators()
+    eng.propagate()
+    eng.synchronize()
+    out_nus, out_en = packet_collection.output_nus, packet_collection.output_energies
+    in_place = all(isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous for a in (out_nus, out_en))
+    res = eng.get_results(out_nus if in_place else None, out_en if in_place else None, track_last_interaction=track)
+    if not in_place:
+        packet_collection.output_nus[:] = res.output_nus
+        packet_collection.output_energies[:] = res.output_energies
+    if track:
+        if isinstance(trackers, st.LastInteractionTrackers):
+            for n in st.LastInteractionTrackers.F64_FIELDS + st.LastInteractionTrackers.I64_FIELDS:
+                getattr(trackers, n)[:] = getattr(res.trackers, n)
+        else:
+            _fill_trackers(trackers, res.trackers)
+    estimators_bulk = st.EstimatorsBulk(res.j_estimator, res.nu_bar_estimator)
+    estimators_line = st.EstimatorsLine(res.j_blue_estimator, res.edotlu_estimator)
+    cfg = montecarlo_configuration
+    if cfg.ENABLE_VPACKET_TRACKING and number_of_vpackets > 0:
+        n = min(res.vpacket_log_count, len(res.vpacket_nus))
+        vt = st.VPacketCollection(-1, spectrum_frequency_grid, cfg.VPACKET_SPAWN_START_FREQUENCY,
+                                  cfg.VPACKET_SPAWN_END_FREQUENCY, -1, n)
+        vt.nus[:] = res.vpacket_nus[:n]
+        vt.energies[:] = res.vpacket_energies[:n]
+        vt.initial_mus[:] = res.vpacket_initial_mus[:n]
+        vt.initial_rs[:] = res.vpacket_initial_rs[:n]
+    else:  # placeholder, as get_vpacket_tracker does (modes/montecarlo_transport.py:228-235)
+        vt = st.VPacketCollection(-1, spectrum_frequency_grid, cfg.VPACKET_SPAWN_START_FREQUENCY,
+                                  cfg.VPACKET_SPAWN_END_FREQUENCY, -1, 1)
+    montecarlo_transport_with_vpackets.last_counters = res.counters
+    montecarlo_transport_with_vpackets.last_kernel_ms = eng.last_propagate_ms()
+    return res.v_packets_energy_hist, vt, estimators_bulk, estimators_line
+
+
+class MonteCarloTransportState:
+    """Result holder with the reference's property names (montecarlo_transport_state.py:15-317), unit-less."""
+
+    def __init__(self, packet_collection, geometry_state_numba, opacity_state_numba, time_explosion):
+        self.packet_collection = packet_collection
+        self.geometry_state_numba = geometry_state_numba
+        self.opacity_state_numba = opacity_state_numba
+        self.time_explosion = time_explosion
+        self.estimators_bulk = None
+        self.estimators_line = None
+        self.vpacket_tracker = None
+        self.tracker_last_interaction = None
+        self.tracker_full_df = None
+        self.enable_full_relativity = False
+        self.virt_logging = False
+
+    output_nu = property(lambda self: self.packet_collection.output_nus)
+    output_energy = property(lambda self: self.packet_collection.output_energies)
+    nu_bar_estimator = property(lambda self: self.estimators_bulk.mean_frequency)
+    j_estimator = property(lambda self: self.estimators_bulk.mean_intensity_total)
+    j_blue_estimator = property(lambda self: self.estimators_line.mean_intensity_blueward)
+    Edotlu_estimator = property(lambda self: self.estimators_line.energy_deposition_line_rate)
+    time_of_simulation = property(lambda self: self.packet_collection.time_of_simulation)
+    packet_luminosity = property(
+        lambda self: self.packet_collection.output_energies / self.packet_collection.time_of_simulation)
+    emitted_packet_mask = property(lambda self: self.packet_collection.output_energies >= 0)
+    emitted_packet_nu = property(lambda self: self.packet_collection.output_nus[self.emitted_packet_mask])
+    reabsorbed_packet_nu = property(lambda self: self.packet_collection.output_nus[~self.emitted_packet_mask])
+    emitted_packet_luminosity = property(lambda self: self.packet_luminosity[self.emitted_packet_mask])
+    reabsorbed_packet_luminosity = property(lambda self: -self.packet_luminosity[~self.emitted_packet_mask])
+    virt_packet_nus = property(lambda self: self.vpacket_tracker.nus)
+    virt_packet_energies = property(lambda self: self.vpacket_tracker.energies)
+    virt_packet_initial_mus = property(lambda self: self.vpacket_tracker.initial_mus)
+    virt_packet_initial_rs = property(lambda self: self.vpacket_tracker.initial_rs)
+
+    @property
+    def tracker_last_interaction_df(self):
+        """Same columns as trackers_last_interaction_to_df (tracker_last_interaction_util.py:33-134)."""
+        import pandas as pd
+
+        t = self.tracker_last_interaction
+        names = {-1: "NO_INTERACTION", 1: "BOUNDARY", 2: "LINE", 4: "ESCATTERING", 8: "CONTINUUM_PROCESS"}
+        it_dtype = pd.CategoricalDtype(categories=["NO_INTERACTION", "BOUNDARY", "LINE", "ESCATTERING", "CONTINUUM_PROCESS"])
+        st_dtype = pd.CategoricalDtype(categories=["IN_PROCESS", "EMITTED", "REABSORBED", "ADIABATIC_COOLING"])
+        n = len(t)
+        return pd.DataFrame(
+            {
+                "event_id": t.interactions_count,
+                "last_interaction_type": pd.Categorical([names[int(v)] for v in t.interaction_type], dtype=it_dtype),
+                "status": pd.Categorical(["IN_PROCESS"] * n, dtype=st_dtype),
+                "radius": t.radius, "shell_id": t.shell_id, "before_nu": t.before_nu, "before_mu": t.before_mu,
+                "before_energy": t.before_energy, "after_nu": t.after_nu, "after_mu": t.after_mu,
+                "after_energy": t.after_energy,
+                "line_absorb_id": pd.array(t.interaction_line_absorb_id, dtype="int64"),
+                "line_emit_id": pd.array(t.interaction_line_emit_id, dtype="int64"),
+            },
+            index=pd.RangeIndex(n, name="packet_id"))
+
+
+class MCTransportSolverHIP:
+    """GPU counterpart of MCTransportSolverClassic (modes/classic/solver.py:46-273), plain-array inputs."""
+
+    def __init__(self, spectrum_frequency_grid, montecarlo_configuration=None, line_interaction_type="macroatom",
+                 enable_full_relativity=False, device_id=None, nthreads=1):
+        self.spectrum_frequency_grid = np.ascontiguousarray(spectrum_frequency_grid, dtype=np.float64)
+        self.montecarlo_configuration = montecarlo_configuration or st.MonteCarloConfiguration()
+        self.line_interaction_type = line_interaction_type
+        self.enable_full_relativity = enable_full_relativity
+        self.nthreads = nthreads  # accepted for API compatibility; the GPU engine ignores it
+        self.device_id = device_id
+        self.transport_state = None
+
+    def initialize_transport_state(self, packet_collection, geometry, opacity_state, time_explosion,
+                                   no_of_virtual_packets=0):
+        cfg = self.montecarlo_configuration
+        cfg.LINE_INTERACTION_TYPE = st.LINE_INTERACTION_TYPES[self.line_interaction_type]
+        cfg.NUMBER_OF_VPACKETS = no_of_virtual_packets
+        cfg.TEMPORARY_V_PACKET_BINS = no_of_virtual_packets
+        cfg.ENABLE_FULL_RELATIVITY = self.enable_full_relativity
+        ts = MonteCarloTransportState(packet_collection, geometry, opacity_state, time_explosion)
+        ts.enable_full_relativity = cfg.ENABLE_FULL_RELATIVITY
+        return ts
+
+    def run(self, transport_state, show_progress_bars=False):
+        return self.run_classic(transport_state, show_progress_bars)
+
+    def run_classic(self, transport_state, show_progress_bars=False):
+        self.transport_state = transport_state
+        cfg = self.montecarlo_configuration
+        n = len(transport_state.packet_collection.initial_nus)
+        trackers = st.LastInteractionTrackers(n)
+        hist, vtracker, est_bulk, est_line = montecarlo_transport_with_vpackets(
+            transport_state.packet_collection, transport_state.geometry_state_numba, float(transport_state.time_explosion),
+            transport_state.opacity_state_numba, cfg, self.spectrum_frequency_grid, trackers, cfg.NUMBER_OF_VPACKETS,
+            show_progress_bars, None, engine=get_engine(self.device_id))
+        transport_state.estimators_bulk = est_bulk
+        transport_state.estimators_line = est_line
+        if cfg.ENABLE_VPACKET_TRACKING and cfg.NUMBER_OF_VPACKETS > 0:
+            transport_state.vpacket_tracker = vtracker
+        transport_state.tracker_last_interaction = trackers
+        transport_state.virt_logging = cfg.ENABLE_VPACKET_TRACKING
+        return hist

@@ -1,0 +1,202 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the CPU oracle and the reference-generated
+golden vectors.  Bars:
+  * integer / index results (status sign, line ids, shell ids, interaction counts): exact;
+  * per-packet floating-point results (output_nus, output_energies, tracker fields, v-packet log): BIT-EXACT vs the
+    oracle in portable-math mode (same arithmetic on both sides), and rtol 1e-13 vs the reference's own output
+    (the reference's regression tolerance, tests/test_montecarlo_main_loop.py);
+  * estimators (J, nu_bar, j_blue, Edotlu, v-hist): atomics change the summation order -> rtol 1e-11.
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import _golden
+from tardis_amd import state as st, synthetic
+
+pytestmark = pytest.mark.gpu
+
+EST_RTOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from tardis_amd.engine import Engine
+    eng = Engine(0)
+    yield eng
+    eng.close()
+
+
+def run_hip(engine, prob, track=True):
+    from tardis_amd import transport
+    pc = prob.packet_collection
+    pc.output_nus[:] = -99.0
+    pc.output_energies[:] = -99.0
+    trackers = st.LastInteractionTrackers(pc.number_of_packets) if track else None
+    hist, vt, eb, el = transport.montecarlo_transport_with_vpackets(
+        pc, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
+        prob.spectrum_frequency_grid, trackers, prob.montecarlo_configuration.NUMBER_OF_VPACKETS, False, None,
+        engine=engine)
+    return hist, vt, eb, el, trackers, transport.montecarlo_transport_with_vpackets.last_counters
+
+
+def run_oracle(oracle, prob, n_threads=1):
+    return oracle.run(prob.packet_collection, prob.geometry, prob.time_explosion, prob.opacity_state,
+                      prob.montecarlo_configuration, prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE,
+                      n_threads=n_threads)
+
+
+def test_device_arithmetic_is_ieee_and_unfused(engine, oracle):
+    rng = np.random.default_rng(7)
+    n = 200_000
+    x = rng.random(n) * 10.0 ** rng.integers(-20, 20, n)
+    y = (rng.random(n) + 1e-3) * 10.0 ** rng.integers(-20, 20, n)
+    assert np.array_equal(engine.debug_eval(0, x, y), x + y)
+    assert np.array_equal(engine.debug_eval(1, x, y), x * y)
+    assert np.array_equal(engine.debug_eval(2, x, y), x / y)
+    assert np.array_equal(engine.debug_eval(3, x), np.sqrt(x))
+    assert np.array_equal(engine.debug_eval(6, x, y), x * y + x)      # a*b+a must not be contracted to an fma
+    assert np.array_equal(engine.debug_eval(8, x - 5.0), np.floor(x - 5.0))
+    xi = rng.random(n)
+    assert np.array_equal(engine.debug_eval(4, xi), oracle.log_array(xi, 1))
+    t = -rng.random(n) * 760.0
+    assert np.array_equal(engine.debug_eval(5, t), oracle.exp_array(t, 1))
+    # edge arguments of the portable log/exp
+    edge = np.array([2.0**-53, 1 - 2.0**-53, 0.5, 0.70710678118654757, 0.7071067811865476, 0.999, 1e-300])
+    assert np.array_equal(engine.debug_eval(4, edge), oracle.log_array(edge, 1))
+    assert engine.debug_eval(4, np.array([0.0]))[0] == -np.inf
+
+
+@pytest.mark.parametrize("seed", [0, 1, 1963, 23111963, 2**32 - 2])
+def test_device_mt19937_matches_numpy_stream(engine, oracle, seed):
+    got = engine.debug_eval(7, np.array([float(seed)]), n=1500)
+    assert np.array_equal(got, oracle.mt19937_random(seed, 1500))
+
+
+@pytest.mark.parametrize("name", _golden.CASES)
+def test_hip_matches_oracle_and_reference_on_golden_cases(engine, oracle, name):
+    prob, g = _golden.load_case(name)
+    ref = run_oracle(oracle, prob)
+    hist, vt, eb, el, trk, counters = run_hip(engine, prob)
+    pc = prob.packet_collection
+    # per-packet: bit-exact vs oracle, 1e-13 vs the reference
+    assert np.array_equal(pc.output_nus, ref.output_nus)
+    assert np.array_equal(pc.output_energies, ref.output_energies)
+    assert_allclose(pc.output_nus, g["output_nus"], rtol=1e-13, atol=0)
+    assert_allclose(pc.output_energies, g["output_energies"], rtol=1e-13, atol=0)
+    for f in _golden.TRACKER_I64:
+        assert np.array_equal(getattr(trk, f), g["trk_" + f]), f
+    for f in _golden.TRACKER_F64:
+        assert np.array_equal(getattr(trk, f), getattr(ref.trackers, f), equal_nan=True), f
+    assert np.all(np.isnan(trk.mu))
+    # estimators
+    stride = int(g["line_estimator_stride"])
+    assert_allclose(eb.mean_intensity_total, ref.j_estimator, rtol=EST_RTOL, atol=0)
+    assert_allclose(eb.mean_frequency, ref.nu_bar_estimator, rtol=EST_RTOL, atol=0)
+    assert_allclose(el.mean_intensity_blueward, ref.j_blue_estimator, rtol=EST_RTOL, atol=0)
+    assert_allclose(el.energy_deposition_line_rate, ref.edotlu_estimator, rtol=EST_RTOL, atol=0)
+    assert_allclose(el.mean_intensity_blueward[::stride], g["j_blue_estimator"], rtol=EST_RTOL, atol=0)
+    assert_allclose(hist, ref.v_packets_energy_hist, rtol=EST_RTOL, atol=0)
+    assert_allclose(hist, g["v_packets_energy_hist"], rtol=EST_RTOL, atol=0)
+    if "vpacket_nus" in g:
+        assert np.array_equal(vt.nus, ref.vpacket_nus) and np.array_equal(vt.energies, ref.vpacket_energies)
+        assert np.array_equal(vt.initial_mus, ref.vpacket_initial_mus) and np.array_equal(vt.initial_rs, ref.vpacket_initial_rs)
+        assert_allclose(vt.nus, g["vpacket_nus"], rtol=1e-13, atol=0)
+    # work counters are integers: exact
+    for k in ("line_visits", "events", "macro_transitions", "vpacket_line_visits", "vpackets", "rng_draws", "packets"):
+        assert counters[k] == ref.counters[k], k
+
+
+@pytest.mark.parametrize("mode,n_v,full", [("downbranch", 0, False), ("macroatom", 0, False), ("scatter", 0, False),
+                                           ("macroatom", 2, False), ("downbranch", 0, True)])
+def test_hip_matches_oracle_on_config1_shape(engine, oracle, mode, n_v, full):
+    """BASELINE configs[0] shape (20 shells, 3e4 lines) at 2e4 packets (2e3 with v-packets)."""
+    prob = synthetic.make_problem(seed=3, n_packets=2_000 if n_v else 20_000, n_shells=20, n_lines=30_000,
+                                  line_interaction_type=mode, n_vpackets=n_v, enable_full_relativity=full)
+    ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
+    hist, vt, eb, el, trk, counters = run_hip(engine, prob)
+    pc = prob.packet_collection
+    assert np.array_equal(pc.output_nus, ref.output_nus)
+    assert np.array_equal(pc.output_energies, ref.output_energies)
+    for f in st.LastInteractionTrackers.I64_FIELDS:
+        assert np.array_equal(getattr(trk, f), getattr(ref.trackers, f)), f
+    assert_allclose(eb.mean_intensity_total, ref.j_estimator, rtol=EST_RTOL)
+    assert_allclose(eb.mean_frequency, ref.nu_bar_estimator, rtol=EST_RTOL)
+    assert_allclose(el.mean_intensity_blueward, ref.j_blue_estimator, rtol=EST_RTOL)
+    assert_allclose(el.energy_deposition_line_rate, ref.edotlu_estimator, rtol=EST_RTOL)
+    assert_allclose(hist, ref.v_packets_energy_hist, rtol=EST_RTOL)
+    assert counters["line_visits"] == ref.counters["line_visits"] and counters["events"] == ref.counters["events"]
+    # the BASELINE parity metric: relative L2 of the real-packet spectrum (target <= 1e-6; here it is exactly 0)
+    from tardis_amd import spectrum
+    a = spectrum.emitted_luminosity_histogram(pc.output_nus, pc.output_energies, pc.time_of_simulation, prob.spectrum_frequency_grid)
+    b = spectrum.emitted_luminosity_histogram(ref.output_nus, ref.output_energies, pc.time_of_simulation, prob.spectrum_frequency_grid)
+    assert spectrum.relative_l2(a, b) <= 1e-6
+
+
+def test_edge_cases(engine, oracle):
+    # empty packet collection
+    prob = synthetic.make_problem(seed=2, n_packets=0, n_shells=4, n_lines=100)
+    hist, vt, eb, el, trk, counters = run_hip(engine, prob)
+    assert counters["packets"] == 0 and not eb.mean_intensity_total.any() and not el.mean_intensity_blueward.any()
+    # one packet, one shell, one line
+    prob = synthetic.make_problem(seed=2, n_packets=1, n_shells=1, n_lines=1, line_interaction_type="scatter")
+    ref = run_oracle(oracle, prob)
+    run_hip(engine, prob)
+    assert np.array_equal(prob.packet_collection.output_nus, ref.output_nus)
+    # ragged count (not a multiple of the wave or block size) and disabled line scattering with tau = 0
+    prob = synthetic.make_problem(seed=5, n_packets=1003, n_shells=7, n_lines=333, line_interaction_type="downbranch",
+                                  disable_line_scattering=True)
+    prob.opacity_state.tau_sobolev[:] = 0.0    # what OpacitySolver does (opacity_solver.py:46-56)
+    ref = run_oracle(oracle, prob)
+    run_hip(engine, prob)
+    assert np.array_equal(prob.packet_collection.output_nus, ref.output_nus)
+    assert np.array_equal(prob.packet_collection.output_energies, ref.output_energies)
+    # electron scattering switched off (sigma_T = 1e-200, solver.py:291-300)
+    prob = synthetic.make_problem(seed=6, n_packets=500, n_shells=5, n_lines=400, line_interaction_type="macroatom")
+    prob.montecarlo_configuration.DISABLE_ELECTRON_SCATTERING = True
+    ref = run_oracle(oracle, prob)
+    run_hip(engine, prob)
+    assert np.array_equal(prob.packet_collection.output_nus, ref.output_nus)
+
+
+def test_error_codes_map_to_reference_exceptions(engine):
+    from tardis_amd.engine import MacroAtomError, MonteCarloException
+    # a zig-zag line list (not sorted descending) makes comov_nu - nu_line negative -> MonteCarloException
+    # (calculate_distances.py:105-106); the oracle fails on the same packet (first_error_packet == 1)
+    prob = synthetic.make_problem(seed=8, n_packets=256, n_shells=3, n_lines=20000, line_interaction_type="scatter")
+    prob.opacity_state.line_list_nu[1::2] *= 1.5
+    with pytest.raises(MonteCarloException) as ei:
+        run_hip(engine, prob)
+    assert ei.value.packet_index == 1
+    # un-normalised transition probabilities (all zero) -> MacroAtomError
+    prob = synthetic.make_problem(seed=9, n_packets=64, n_shells=3, n_lines=200, line_interaction_type="downbranch",
+                                  log_tau_mean=1.0)
+    prob.opacity_state.transition_probabilities[:] = 0.0
+    with pytest.raises(MacroAtomError) as ei:
+        run_hip(engine, prob)
+    assert ei.value.packet_index == 3
+
+
+def test_partition_invariance_and_determinism(engine):
+    """Size-independent properties used at BASELINE scale: per-packet results do not depend on how packets are
+    batched or scheduled; estimators add across batches."""
+    prob = synthetic.make_problem(seed=4, n_packets=50_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+    hist, vt, eb, el, _, c_all = run_hip(engine, prob, track=False)
+    nus, ens = prob.packet_collection.output_nus.copy(), prob.packet_collection.output_energies.copy()
+    run_hip(engine, prob, track=False)
+    assert np.array_equal(nus, prob.packet_collection.output_nus)          # run-to-run determinism
+    J = np.zeros_like(eb.mean_intensity_total)
+    jb = np.zeros_like(el.mean_intensity_blueward)
+    visits = 0
+    full = prob.packet_collection
+    for r in range(3):
+        prob.packet_collection = full.shard(r, 3)
+        _, _, eb_r, el_r, _, c_r = run_hip(engine, prob, track=False)
+        J += eb_r.mean_intensity_total
+        jb += el_r.mean_intensity_blueward
+        visits += c_r["line_visits"]
+    prob.packet_collection = full
+    assert np.array_equal(full.output_nus, nus) and np.array_equal(full.output_energies, ens)
+    assert_allclose(J, eb.mean_intensity_total, rtol=EST_RTOL)
+    assert_allclose(jb, el.mean_intensity_blueward, rtol=EST_RTOL)
+    assert visits == c_all["line_visits"]
+    assert not np.any(full.output_energies == -99.0)

@@ -1,0 +1,71 @@
+"""GPU-box experiment driver (design input, not a test): memory-system micro-benchmarks and kernel-time ablations.
+    python tools/gpu_experiments.py [micro] [ablate] [scale]
+Writes human-readable tables to stdout."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from tardis_amd import synthetic  # noqa: E402
+from tardis_amd.engine import Engine  # noqa: E402
+
+what = set(sys.argv[1:]) or {"micro", "ablate"}
+eng = Engine(0)
+
+if "micro" in what:
+    names = {0: "atomic f64 random, agent scope", 1: "atomic f64 random, wg scope, XCD slice",
+             2: "atomic f64 16-coalesced, agent", 3: "atomic f64 16-coalesced, wg scope, XCD slice",
+             4: "load 8B random", 5: "load 8B 16-coalesced"}
+    blocks, iters = 2048, 256
+    nops = blocks * 256 * iters
+    for n in (600_000, 20_000_000, 200_000_000):
+        for which in range(6):
+            ms = eng.debug_microbench(which, n, iters, blocks)
+            print(f"micro n={n * 8 / 1e6:8.1f} MB  {names[which]:46s} {ms:9.3f} ms  {nops / ms / 1e6:9.2f} Gop/s", flush=True)
+
+def run(P, flags=0, bpc=8, copies=1, track=1, kw=None, reps=2, variant=1):
+    kw = kw or dict(n_shells=20, n_lines=30000, line_interaction_type="downbranch")
+    prob = run.cache.get((P, tuple(sorted(kw.items()))))
+    if prob is None:
+        prob = synthetic.make_problem(seed=1, n_packets=P, **kw)
+        run.cache[(P, tuple(sorted(kw.items())))] = prob
+    eng.set_option("variant", variant)
+    eng.set_option("debug_flags", flags)
+    eng.set_option("blocks_per_cu", bpc)
+    eng.set_option("estimator_copies", copies)
+    eng.set_option("track_last_interaction", track)
+    eng.set_geometry(prob.geometry, prob.time_explosion)
+    eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+    eng.set_packets(prob.packet_collection)
+    best = 1e30
+    for _ in range(reps):
+        eng.reset_estimators()
+        eng.propagate()
+        eng.synchronize()
+        best = min(best, eng.last_propagate_ms())
+    return best
+run.cache = {}
+
+if "ablate" in what:
+    for P in (1_000_000, 10_000_000):
+        for variant in (0, 1):
+            for bpc in ((8,) if variant == 0 else (1, 2, 4)):
+                ms = run(P, 0, bpc, variant=variant)
+                print(f"ablate P={P:>9d} variant={variant} blocks/CU={bpc:2d} flags=0 track=1: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
+        for flags in (1, 3):
+            ms = run(P, flags, 4, variant=1)
+            print(f"ablate P={P:>9d} variant=1 blocks/CU= 4 flags={flags} track=1: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
+        ms = run(P, 0, 4, track=0, variant=1)
+        print(f"ablate P={P:>9d} variant=1 blocks/CU= 4 flags=0 track=0: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
+
+if "scale" in what:
+    kw = dict(n_shells=20, n_lines=500000, line_interaction_type="macroatom")
+    for P in (200_000, 2_000_000):
+        for variant in (0, 1):
+            ms = run(P, 0, 8 if variant == 0 else 4, kw=kw, reps=1, variant=variant)
+            print(f"config3-shape P={P} variant={variant}: {ms:9.2f} ms {P / ms / 1e3:8.3f} Mpkt/s", flush=True)
+eng.close()
