@@ -1,27 +1,26 @@
-// propagate_group.hpp -- cooperative propagation kernel (variant 1): 16 lanes per packet.
+// propagate_group.hpp -- cooperative propagation kernel (variant 1): G = 16 or 8 lanes per packet.
 //
 // Why: the dominant cost of the lane-per-packet kernel is the 2 scattered fp64 atomics per line visit (measured
 // ceiling on MI355X: ~24 G random fp64 atomics/s chip-wide, but ~170 G/s when 16 lanes hit 16 consecutive doubles,
-// profiles/r01_microbench.txt).  Here a 16-lane group (one DPP row, four groups per wave) owns one packet and sweeps
-// the sorted line list 16 lines at a time:
-//   * nu_line[cur..cur+15] and tau[shell][cur..cur+15] are two coalesced 128-byte loads,
+// profiles/r01_microbench_and_ablation_lane_kernel.txt).  Here a G-lane group owns one packet and sweeps the sorted
+// line list G lines at a time:
+//   * nu_line[cur..cur+G) and tau[shell][cur..cur+G) are two coalesced loads (the next chunk is prefetched),
 //   * every lane evaluates "its" line (distance, estimator energy),
 //   * the running Sobolev optical depth is carried across lanes IN THE REFERENCE'S SERIAL ORDER (bit-exact),
-//   * a 16-bit ballot picks the first line at which the reference's loop would have stopped,
-//   * lanes before it issue the j_blue / Edotlu atomics as 128-byte-contiguous groups.
-// The packet's scalar event code (boundary distance, tau_event, move, scatter, macro atom) is executed redundantly
-// by the 16 lanes, so no cross-lane traffic is needed for it.  The packet's MT19937 state lives in LDS (2496 B per
-// group) and is regenerated cooperatively 16 words at a time; raw seeded states are produced by a separate
-// lane-per-packet kernel (the init_genrand recurrence is serial per packet).
+//   * a ballot picks the first line at which the reference's loop would have stopped,
+//   * lanes before it issue the j_blue / Edotlu atomics as contiguous groups.
+// The packet's scalar event code (boundary distance, tau_event, move, scatter) is executed redundantly by the G
+// lanes, so no cross-lane traffic is needed for it; the macro-atom block walk is cooperative again.  The packet's
+// MT19937 state stays in global memory and is regenerated cooperatively G words at a time; raw seeded
+// states are produced by a separate lane-per-packet kernel (the init_genrand recurrence is serial per packet).
+// The last-interaction tracker lives in LDS (written by lane 0 on interactions only).
 #pragma once
 #include "mc_device.hpp"
-#include "propagate_lane.hpp"  // Tracker, xcc_id
+#include "propagate_lane.hpp"  // xcc_id
 
 namespace mc {
 
-constexpr int GROUP = 16;
-constexpr int GROUPS_PER_BLOCK = 16;   // 256 threads
-constexpr int PACKET_BATCH = 16;       // packets reserved per global atomic
+constexpr int PACKET_BATCH = 16;  // packets reserved per global atomic
 
 // ---- seeding kernel: raw init_genrand state, [packet][624] contiguous, one packet per lane.
 // Stores go through an LDS tile so that a 16-lane group writes 64 contiguous bytes of one packet's state.
@@ -53,54 +52,102 @@ __global__ void __launch_bounds__(256) seed_states_kernel(const uint32_t *__rest
     }
 }
 
-// ---- MT19937 in LDS, one state per 16-lane group, all lanes of the group call every method together
+// ---- MT19937, one stream per packet.  The 624-word state stays in the packet's slot of the seeded-state buffer
+// (global memory, touched by this group only) and is regenerated in place G words at a time with coalesced group
+// loads/stores; the freshly regenerated block also stays in registers (one word per lane), so a draw is two
+// cross-lane reads and no memory access.  No LDS is needed, which is what lets many groups share a CU.
+template <int G>
 struct GroupRng {
-    uint32_t *mt;    // LDS, 624 words
-    int idx;         // next output word (group-uniform)
-    int fresh;       // words [0, fresh) of the current generation are already regenerated (group-uniform)
-    long long draws;
+    uint32_t *st;    // this packet's 624-word state (global)
+    uint32_t blk;    // word (fresh - G + j) of the current generation (untempered), valid once fresh > 0
+    int idx;         // next output word (group-uniform, even)
+    int fresh;       // words [0, fresh) of the current generation are regenerated (group-uniform, multiple of G)
+    int draws;
 
-    __device__ __forceinline__ void regenerate16(int j)
-    {   // regenerate words [fresh, fresh+16) in place; fresh is a multiple of 16 and 624 = 39*16
+    __device__ __forceinline__ void attach(uint32_t *state) { st = state; idx = 0; fresh = 0; blk = 0; }
+    __device__ __forceinline__ void regenerate(int j)
+    {   // words [fresh, fresh+G) of the next generation; 624 = 39*16 = 78*8
+        if (fresh == MT_N) fresh = 0;
         const int k = fresh + j;
         const int k1 = (k + 1 == MT_N) ? 0 : k + 1;
         const int km = (k + 397 >= MT_N) ? k + 397 - MT_N : k + 397;
-        const uint32_t a = mt[k], b = mt[k1], c = mt[km];
+        // make this wave's earlier stores to the state visible to these loads (same wave: waitcnt only)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t a = st[k], b = st[k1], c = st[km];
         uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
         uint32_t v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        // word 623 needs the NEW word 0 (already regenerated); every other k+1 must be the OLD value, which is
-        // guaranteed because all 16 reads above are issued before the 16 writes below.
-        mt[k] = v;
-        fresh += 16;
-    }
-    __device__ __forceinline__ uint32_t next_u32(int j)
-    {
-        if (idx == MT_N) { idx = 0; fresh = 0; }
-        if (idx >= fresh) regenerate16(j);
-        uint32_t v = mt[idx++];
-        v ^= v >> 11;
-        v ^= (v << 7) & 0x9d2c5680u;
-        v ^= (v << 15) & 0xefc60000u;
-        v ^= v >> 18;
-        return v;
+        // word 623 needs the NEW word 0 (regenerated 38 steps ago); every other k+1 must be the OLD value, which
+        // holds because all G loads above are issued before the G stores below (same wave, program order).
+        st[k] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        blk = v;
+        fresh += G;
     }
     __device__ __forceinline__ double random(int j)
     {
-        uint32_t a = next_u32(j) >> 5, b = next_u32(j) >> 6;
+        if (idx == MT_N) idx = 0;
+        if (idx == fresh || (fresh == MT_N && idx == 0)) regenerate(j);
+        const int w = idx & (G - 1);
+        uint32_t a = (uint32_t)__shfl((int)blk, w, G), b = (uint32_t)__shfl((int)blk, w + 1, G);
+        idx += 2;
+        a ^= a >> 11; a ^= (a << 7) & 0x9d2c5680u; a ^= (a << 15) & 0xefc60000u; a ^= a >> 18;
+        b ^= b >> 11; b ^= (b << 7) & 0x9d2c5680u; b ^= (b << 15) & 0xefc60000u; b ^= b >> 18;
+        a >>= 5; b >>= 6;
         ++draws;
         return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
     }
 };
 
-__device__ __forceinline__ double group_bcast(double v, int src) { return __shfl(v, src, GROUP); }
-__device__ __forceinline__ int group_bcast(int v, int src) { return __shfl(v, src, GROUP); }
+// last-interaction tracker in LDS (packets/trackers/tracker_last_interaction.py:8-254), one per group
+struct LdsTracker {
+    double radius, nu, energy, before_nu, before_mu, before_energy, after_nu, after_mu, after_energy;
+    int shell_id, interaction_type, line_absorb_id, line_emit_id, interactions_count, boundary_buffer;
+    int pad[2];
+};
 
-struct GroupCounters { unsigned long long visits = 0, events = 0, macro = 0; };
+template <int G> __device__ __forceinline__ double gbcast(double v, int src) { return __shfl(v, src, G); }
+template <int G> __device__ __forceinline__ int gbcast(int v, int src) { return __shfl(v, src, G); }
+
+// lane j <- value of lane j-1 of its 16-lane DPP row; lane 0 of the row keeps `first`
+__device__ __forceinline__ double dpp_row_shr1(double first, double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(first), __double2loint(v), 0x111, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// ((carry + v0) + v1) + ... + vj for lane j: the reference's sequential accumulation order, evaluated exactly.
+// acc <- shr1(acc) + v repeated G-1 times: after step s lanes 0..s hold their final value and recomputing a final
+// lane from its (final) left neighbour reproduces the same value, so no per-step masking is needed.
+template <int G>
+__device__ __forceinline__ double serial_prefix(double carry, double v, int j)
+{
+    const double head = carry + v;  // value of the group's first lane
+    double acc = head;
+#pragma unroll
+    for (int s = 1; s < G; ++s) {
+        double prev = dpp_row_shr1(carry, acc);
+        acc = prev + v;
+        if (G < 16) acc = (j == 0) ? head : acc;  // an 8-lane group must not read across into its row neighbour
+    }
+    return acc;
+}
+
+// value of the left neighbour in the group (lane 0 gets `first`)
+template <int G>
+__device__ __forceinline__ double group_shr1(double first, double v, int j)
+{
+    double r = dpp_row_shr1(first, v);
+    if (G < 16) r = (j == 0) ? first : r;
+    return r;
+}
+
+struct GroupCounters { unsigned long long visits = 0; unsigned events = 0, macro = 0; };
 
 // ---- one cooperative trace_packet (modes/homologous_rad_packet_transport.py:30-174)
 // All arguments / results are group-uniform except the lane index j.  Returns 0 or a negative error code.
-template <bool FULL>
-__device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet &p, GroupRng &rng, const int j,
+template <bool FULL, int G>
+__device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet &p, GroupRng<G> &rng, const int j,
                                                   const double chi_cont, double *__restrict__ jb, double *__restrict__ ed,
                                                   double &distance, int &type, int &delta_shell, GroupCounters &cn)
 {
@@ -108,7 +155,7 @@ __device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet
     const double t = P.t_exp;
     const int start = p.next_line_id;
     const double *__restrict__ tau_row = P.tau_t + (size_t)p.shell * L;
-    // software prefetch of the first chunk: the loads fly while the scalar prologue (sqrt, log) runs
+    // software pipeline: chunk c+1 is loaded while chunk c is evaluated; the first loads fly during the prologue
     int line = start + j;
     bool in_range = line < L;
     double nu_line = in_range ? P.nu_line[line] : 0.0;
@@ -125,47 +172,47 @@ __device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet
     double *__restrict__ jb_row = jb + (size_t)p.shell * L;
     double *__restrict__ ed_row = ed + (size_t)p.shell * L;
     const int last = L - 1;
-    const int lane = threadIdx.x & 63;
-    const int gshift = lane & 48;
-    double tau_carry = 0.0;               // tau_trace_line_combined before the first line of this chunk
+    const int gshift = (threadIdx.x & 63) & ~(G - 1);
+    constexpr unsigned long long GMASK = (G == 16) ? 0xffffull : 0xffull;
+    double tau_carry = 0.0;                      // tau_trace_line_combined before the first line of this chunk
     double d_cont_carry = tau_event / chi_cont;  // distance_continuous in force at the first line of this chunk
     cn.events++;
 
-    for (int cur0 = start; cur0 < L; cur0 += GROUP) {
-        if (cur0 != start) {  // later chunks: plain loads (prefetched only for the first one)
-            line = cur0 + j;
-            in_range = line < L;
-            nu_line = in_range ? P.nu_line[line] : 0.0;
-            tau_line = in_range ? tau_row[line] : 0.0;
-        }
-        // --- serial-order inclusive prefix of tau over the chunk: ((carry + t0) + t1) + ... + tj
-        double tau_incl = tau_carry;
-#pragma unroll
-        for (int i = 0; i < GROUP; ++i) {
-            double ti = group_bcast(tau_line, i);
-            tau_incl = tau_incl + ((j >= i) ? ti : 0.0);
-        }
-        double tau_prev = __shfl_up(tau_incl, 1, GROUP);  // tau_trace_line_combined before this lane's line
-        // distance_continuous in force when this lane's line is examined
+    for (int cur0 = start; cur0 < L; cur0 += G) {
+        // prefetch the next chunk
+        const int nline = cur0 + G + j;
+        const bool nin = nline < L;
+        const double nu_next = nin ? P.nu_line[nline] : 0.0;
+        const double tau_next = nin ? tau_row[nline] : 0.0;
+
+        const double tau_incl = serial_prefix<G>(tau_carry, tau_line, j);
+        const double tau_prev = group_shr1<G>(tau_carry, tau_incl, j);  // tau_trace_line_combined before this lane's line
         const double d_cont = (j == 0) ? d_cont_carry : (tau_event - tau_prev) / chi_cont;
-        // --- this lane's line
-        double d_trace = 0.0;
-        bool err = false;
-        if (in_range) err = !distance_line<FULL>(p.nu, p.r, p.mu, comov_nu, line == last, nu_line, t, d_trace);
+        // calculate_distance_line (calculate_distances.py:66-112), select form
+        const bool is_last = line == last;
+        const double nu_diff = comov_nu - nu_line;
+        const double q = nu_diff / p.nu;
+        const bool close = fabs(q) < CLOSE_LINE_THRESHOLD;
+        const bool err = in_range && !is_last && !close && !(nu_diff >= 0);
+        double d_far;
+        if (FULL) d_far = distance_line_full_relativity(nu_line, p.nu, t, p.r, p.mu);
+        else d_far = q * C_LIGHT * t;
+        const double d_trace = is_last ? MISS_DISTANCE : (close ? 0.0 : d_far);
         const double tau_combined = tau_incl + chi_cont * d_trace;
         double dmin = d_trace;  // Python min(d_trace, d_boundary, d_cont)
         if (d_boundary < dmin) dmin = d_boundary;
         if (d_cont < dmin) dmin = d_cont;
-        const bool stop_b = in_range && !err && d_trace != 0 && dmin == d_boundary;
-        const bool stop_e = in_range && !err && d_trace != 0 && !stop_b && dmin == d_cont;
-        const bool stop_l = in_range && !err && !stop_b && !stop_e && tau_combined > tau_event && !P.disable_line_scattering;
+        const bool ok = in_range && !err;
+        const bool stop_b = ok && d_trace != 0 && dmin == d_boundary;
+        const bool stop_e = ok && d_trace != 0 && !stop_b && dmin == d_cont;
+        const bool stop_l = ok && !stop_b && !stop_e && tau_combined > tau_event && !P.disable_line_scattering;
         const bool stop = stop_b || stop_e || stop_l || (in_range && err);
-        const unsigned stop_mask = (unsigned)((__ballot(stop) >> gshift) & 0xffffull);
-        const int first = stop_mask ? __builtin_ctz(stop_mask) : GROUP;  // group-uniform
+        const unsigned stop_mask = (unsigned)((__ballot(stop) >> gshift) & GMASK);
+        const int first = stop_mask ? __builtin_ctz(stop_mask) : G;  // group-uniform
+        const int code = stop_b ? 1 : (stop_e ? 2 : (stop_l ? 3 : ((in_range && err) ? 4 : 0)));
+        const int first_code = gbcast<G>(code, first & (G - 1));
         // lines before the stopping one are passed (estimators updated); a LINE stop updates its own line too
-        const int first_l = group_bcast((int)stop_l, first & 15);
-        const bool first_is_line = (first < GROUP) && first_l;
-        const bool visited = in_range && (j < first || (j == first && first_is_line));
+        const bool visited = in_range && (j < first || (j == first && first_code == 3));
         if (visited && !(P.debug_flags & 1)) {
             double energy;
             if (!FULL) energy = p.energy * (1.0 - ((d_trace + mur) / tc));
@@ -173,22 +220,21 @@ __device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet
             atomic_add_f64(&jb_row[line], energy / p.nu);
             atomic_add_f64(&ed_row[line], energy);
         }
-        if (first < GROUP) {
-            const int n_in = min(first + 1, L - cur0);
-            cn.visits += (unsigned long long)n_in;
-            if (group_bcast((int)err, first)) return ERR_MONTECARLO;
+        if (first < G) {
+            cn.visits += (unsigned long long)(first + 1);
+            if (first_code == 4) return ERR_MONTECARLO;
             p.next_line_id = cur0 + first;
-            const int sb = group_bcast((int)stop_b, first), se = group_bcast((int)stop_e, first);
-            if (sb) { type = IT_BOUNDARY; distance = d_boundary; }
-            else if (se) { type = IT_ESCATTERING; distance = group_bcast(d_cont, first); }
-            else { type = IT_LINE; distance = group_bcast(d_trace, first); }
+            if (first_code == 1) { type = IT_BOUNDARY; distance = d_boundary; }
+            else if (first_code == 2) { type = IT_ESCATTERING; distance = gbcast<G>(d_cont, first); }
+            else { type = IT_LINE; distance = gbcast<G>(d_trace, first); }
             return 0;
         }
         // whole chunk passed: carry the running optical depth and the continuum distance into the next chunk
-        const int n_in = min(GROUP, L - cur0);
+        const int n_in = min(G, L - cur0);
         cn.visits += (unsigned long long)n_in;
-        tau_carry = group_bcast(tau_incl, n_in - 1);
+        tau_carry = gbcast<G>(tau_incl, n_in - 1);
         d_cont_carry = (tau_event - tau_carry) / chi_cont;
+        line = nline; in_range = nin; nu_line = nu_next; tau_line = tau_next;
     }
     // for-else (lines 157-172): the line list is exhausted; next_line_id is left untouched
     if (d_cont_carry < d_boundary) { distance = d_cont_carry; type = IT_ESCATTERING; }
@@ -196,55 +242,77 @@ __device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet
     return 0;
 }
 
-// macro_atom_interaction (macro_atom.py:52-104); scalar walk executed redundantly by the group (block sizes are small)
-__device__ inline int macro_atom_group(const DeviceProblem &P, GroupRng &rng, const int j, int level, int shell, int &out_line,
-                                       int &out_type, GroupCounters &cn)
+// macro_atom_interaction (macro_atom.py:52-104): the transition block of the activated level is loaded G
+// probabilities at a time, accumulated in the reference's serial order, and a ballot finds the selected row.
+template <int G>
+__device__ __forceinline__ int macro_atom_group(const DeviceProblem &P, GroupRng<G> &rng, const int j, int level, int shell,
+                                                int &out_line, GroupCounters &cn)
 {
-    const double *prob_row = P.prob_t + (size_t)shell * P.n_trans;
+    const double *__restrict__ prob_row = P.prob_t + (size_t)shell * P.n_trans;
+    const int gshift = (threadIdx.x & 63) & ~(G - 1);
+    constexpr unsigned long long GMASK = (G == 16) ? 0xffffull : 0xffull;
     int ttype = 0, tid = -1;
     while (ttype >= 0) {
-        double probability = 0.0;
-        double event = rng.random(j);
-        int b0 = P.block_edge[level], b1 = P.block_edge[level + 1];
+        const double event = rng.random(j);
+        const int b0 = P.block_edge[level], b1 = P.block_edge[level + 1];
+        double carry = 0.0;
         bool found = false;
-        for (tid = b0; tid < b1; ++tid) {
-            cn.macro++;
-            probability += prob_row[tid];
-            if (probability > event) {
-                level = P.dest[tid];
-                ttype = P.ttype[tid];
+        for (int base = b0; base < b1; base += G) {
+            const int k = base + j;
+            const bool in = k < b1;
+            const double pr = in ? prob_row[k] : 0.0;
+            const double acc = serial_prefix<G>(carry, pr, j);
+            const unsigned hit = (unsigned)((__ballot(in && acc > event) >> gshift) & GMASK);
+            if (hit) {
+                const int f = __builtin_ctz(hit);
+                tid = base + f;
+                cn.macro += (unsigned)(f + 1);
                 found = true;
                 break;
             }
+            const int n_in = min(G, b1 - base);
+            cn.macro += (unsigned)n_in;
+            carry = gbcast<G>(acc, n_in - 1);
         }
         if (!found) return ERR_MACRO_ATOM;
+        level = P.dest[tid];
+        ttype = P.ttype[tid];
     }
+    if (ttype != -1) return ERR_UNSUPPORTED;
     out_line = P.tline[tid];
-    out_type = ttype;
     return 0;
 }
 
-template <bool FULL, bool TRACK>
-__global__ void __launch_bounds__(256) propagate_group_kernel(DeviceProblem P, const uint32_t *__restrict__ seeded_states,
-                                                              long long chunk_first, long long chunk_count)
+template <int G, int BLOCK>
+__host__ __device__ constexpr size_t group_kernel_lds_bytes(int n_shells)
 {
+    return (size_t)(BLOCK / G) * sizeof(LdsTracker) + 2 * (size_t)n_shells * sizeof(double);
+}
+
+template <bool FULL, bool TRACK, int G, int BLOCK, int OCC>
+__global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(DeviceProblem P, uint32_t *__restrict__ seeded_states,
+                                                                long long chunk_first, long long chunk_count)
+{
+    constexpr int NGROUPS = BLOCK / G;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    uint32_t *lds_mt = reinterpret_cast<uint32_t *>(lds_raw);                       // [16 groups][624]
-    double *lds_J = reinterpret_cast<double *>(lds_raw + GROUPS_PER_BLOCK * MT_N * 4);  // [S]
+    LdsTracker *lds_trk = reinterpret_cast<LdsTracker *>(lds_raw);    // [NGROUPS]
+    double *lds_J = reinterpret_cast<double *>(lds_raw + NGROUPS * sizeof(LdsTracker));
     double *lds_nubar = lds_J + P.n_shells;
-    for (int s = threadIdx.x; s < 2 * P.n_shells; s += blockDim.x) lds_J[s] = 0.0;
+    for (int s = threadIdx.x; s < 2 * P.n_shells; s += BLOCK) lds_J[s] = 0.0;
     __syncthreads();
 
-    const int j = threadIdx.x & (GROUP - 1);
-    const int g = threadIdx.x >> 4;
+    const int j = threadIdx.x & (G - 1);
+    const int g = threadIdx.x / G;
+    const int lane = threadIdx.x & 63;
     const int copy = P.n_est_copies > 1 ? (xcc_id() % P.n_est_copies) : 0;
     double *jb = P.jblue_t + (size_t)copy * P.est_copy_stride;
     double *ed = P.edot_t + (size_t)copy * P.est_copy_stride;
     const double t = P.t_exp;
 
-    GroupRng rng;
-    rng.mt = lds_mt + g * MT_N;
-    rng.idx = 0; rng.fresh = 0; rng.draws = 0;
+    GroupRng<G> rng;
+    rng.attach(seeded_states);
+    rng.draws = 0;
+    LdsTracker &trk = lds_trk[g];
     GroupCounters cn;
     unsigned long long draws_total = 0;
 
@@ -252,14 +320,11 @@ __global__ void __launch_bounds__(256) propagate_group_kernel(DeviceProblem P, c
     // batch_next / batch_end / exhausted are wave-uniform and only modified in wave-uniform control flow.
     long long batch_next = 0, batch_end = 0;
     bool exhausted = false;
-    const int lane = threadIdx.x & 63;
     Packet p;
     p.status = ST_EMITTED;  // "needs a packet"
     p.r = p.mu = p.nu = p.energy = 0.0; p.shell = 0; p.next_line_id = 0;
     long long pkt = -1;
     bool done = false;      // this group has no more work
-    Tracker trk;
-    if (TRACK) trk.init();
 
     for (;;) {
         // ---------------------------------------------------------------- fetch packets (wave-uniform step)
@@ -285,20 +350,26 @@ __global__ void __launch_bounds__(256) propagate_group_kernel(DeviceProblem P, c
                 batch_next += take;
                 served += take;
             }
-            mine = __shfl(mine, 0, GROUP);
+            mine = __shfl(mine, 0, G);
             if (need) {
                 if (mine < 0) done = true;
                 else {
                     pkt = mine;
-                    // load the seeded MT state (2496 contiguous bytes) into LDS: 39 coalesced 64-byte group loads
-                    const uint32_t *src = seeded_states + (size_t)pkt * MT_N;
-                    for (int k = j; k < MT_N; k += GROUP) rng.mt[k] = src[k];
                     draws_total += (unsigned long long)rng.draws;
-                    rng.idx = 0; rng.fresh = 0; rng.draws = 0;
+                    rng.attach(seeded_states + (size_t)pkt * MT_N);
+                    rng.draws = 0;
                     const long long i = chunk_first + pkt;
                     p.r = P.r0[i]; p.mu = P.mu0[i]; p.nu = P.nu0[i]; p.energy = P.e0[i];
                     p.shell = 0; p.status = ST_IN_PROCESS;
-                    if (TRACK) trk.init();
+                    if (TRACK && j == 0) {
+                        const double nan = __builtin_nan("");
+                        trk.radius = trk.nu = trk.energy = nan;
+                        trk.before_nu = trk.before_mu = trk.before_energy = nan;
+                        trk.after_nu = trk.after_mu = trk.after_energy = nan;
+                        trk.shell_id = -1; trk.interaction_type = -1; trk.line_absorb_id = -1; trk.line_emit_id = -1;
+                        trk.interactions_count = 0;
+                        trk.boundary_buffer = 0;  // -1 + the initial track_boundary_event
+                    }
                     {   // set_packet_props_{partial,full}_relativity (classic/packet_propagation.py:254-318)
                         double velocity = p.r / t;
                         double inv = inverse_doppler_factor<FULL>(velocity, p.mu);
@@ -319,7 +390,6 @@ __global__ void __launch_bounds__(256) propagate_group_kernel(DeviceProblem P, c
                         if (lo == P.n_lines) lo -= 1;
                         p.next_line_id = lo;
                     }
-                    if (TRACK) trk.boundary_buffer += 1;
                 }
             }
         }
@@ -333,7 +403,7 @@ __global__ void __launch_bounds__(256) propagate_group_kernel(DeviceProblem P, c
         if (FULL) chi_e *= dop;
         double distance;
         int type = 0, delta = 0;
-        int err = trace_packet_group<FULL>(P, p, rng, j, chi_e, jb, ed, distance, type, delta, cn);
+        int err = trace_packet_group<FULL, G>(P, p, rng, j, chi_e, jb, ed, distance, type, delta, cn);
         if (!err) {
             // move_r_packet + update_estimators_bulk (packets/movement.py:31-76)
             double r = p.r;
@@ -351,61 +421,42 @@ __global__ void __launch_bounds__(256) propagate_group_kernel(DeviceProblem P, c
                 p.r = new_r;
             }
             if (type == IT_BOUNDARY) {
-                if (TRACK) trk.boundary_buffer += 1;
+                if (TRACK && j == 0) trk.boundary_buffer += 1;
                 cross_shell(p.shell, p.status, delta, P.n_shells);
-            } else if (type == IT_LINE) {
-                if (TRACK) {
-                    trk.before_nu = p.nu; trk.before_mu = p.mu; trk.before_energy = p.energy;
-                    trk.line_absorb_id = p.next_line_id;
-                }
-                // line_scatter_event (interaction_event_callers.py:187-239)
-                double vel = p.r / t;
-                double old_dop = doppler_factor<FULL>(vel, p.mu);
-                p.mu = 2.0 * rng.random(j) - 1.0;
-                double inv_new = inverse_doppler_factor<FULL>(vel, p.mu);
-                double comov_energy = p.energy * old_dop;
-                p.energy = comov_energy * inv_new;
-                int emit = p.next_line_id;
-                if (P.line_interaction_type != 0) {
-                    double comov_nu = p.nu * old_dop;
-                    p.nu = comov_nu * inv_new;
-                    int ttype;
-                    err = macro_atom_group(P, rng, j, P.line2level[p.next_line_id], p.shell, emit, ttype, cn);
-                    if (!err && ttype != -1) err = ERR_UNSUPPORTED;
-                }
-                if (!err) {
-                    // line_emission (interaction_events.py:227-258)
-                    double inv = inverse_doppler_factor<FULL>(p.r / t, p.mu);
-                    p.nu = P.nu_line[emit] * inv;
-                    p.next_line_id = emit + 1;
-                    if (FULL) p.mu = aberration_cmf_to_lf(p.r, t, p.mu);
-                    if (TRACK) {
-                        trk.after_nu = p.nu; trk.after_mu = p.mu; trk.after_energy = p.energy;
-                        trk.line_emit_id = p.next_line_id - 1;
-                        trk.interactions_count += 1 + trk.pop();
-                        trk.radius = p.r; trk.nu = p.nu; trk.energy = p.energy; trk.shell_id = p.shell;
-                        trk.interaction_type = IT_LINE;
-                    }
-                }
-            } else {  // IT_ESCATTERING: thomson_scatter (interaction_events.py:184-217)
-                if (TRACK) {
-                    trk.before_mu = p.mu; trk.before_nu = p.nu; trk.before_energy = p.energy;
-                    trk.line_absorb_id = -1; trk.line_emit_id = -1;
-                }
+            } else {
+                const double before_nu = p.nu, before_mu = p.mu, before_energy = p.energy;
+                const int absorb = (type == IT_LINE) ? p.next_line_id : -1;
+                int emit_id = -1;
+                // common part of line_scatter_event (interaction_event_callers.py:187-239) and thomson_scatter
+                // (interaction_events.py:184-217): Doppler with the old angle, new isotropic angle, Doppler back
                 double vel = p.r / t;
                 double old_dop = doppler_factor<FULL>(vel, p.mu);
                 double comov_nu = p.nu * old_dop;
                 double comov_energy = p.energy * old_dop;
                 p.mu = 2.0 * rng.random(j) - 1.0;
                 double inv_new = inverse_doppler_factor<FULL>(vel, p.mu);
-                p.nu = comov_nu * inv_new;
                 p.energy = comov_energy * inv_new;
-                if (FULL) p.mu = aberration_cmf_to_lf(p.r, t, p.mu);
-                if (TRACK) {
-                    trk.after_mu = p.mu; trk.after_nu = p.nu; trk.after_energy = p.energy;
-                    trk.interactions_count += 1 + trk.pop();
+                if (type == IT_LINE) {
+                    int emit = p.next_line_id;
+                    if (P.line_interaction_type != 0)
+                        err = macro_atom_group<G>(P, rng, j, P.line2level[p.next_line_id], p.shell, emit, cn);
+                    if (!err) {  // line_emission (interaction_events.py:227-258); its inverse Doppler factor == inv_new
+                        p.nu = P.nu_line[emit] * inv_new;
+                        p.next_line_id = emit + 1;
+                        emit_id = emit;
+                    }
+                } else {
+                    p.nu = comov_nu * inv_new;
+                }
+                if (FULL && !err) p.mu = aberration_cmf_to_lf(p.r, t, p.mu);
+                if (TRACK && j == 0 && !err) {
+                    trk.before_nu = before_nu; trk.before_mu = before_mu; trk.before_energy = before_energy;
+                    trk.line_absorb_id = absorb; trk.line_emit_id = emit_id;
+                    trk.after_nu = p.nu; trk.after_mu = p.mu; trk.after_energy = p.energy;
+                    trk.interactions_count += 1 + trk.boundary_buffer;
+                    trk.boundary_buffer = 0;
                     trk.radius = p.r; trk.nu = p.nu; trk.energy = p.energy; trk.shell_id = p.shell;
-                    trk.interaction_type = IT_ESCATTERING;
+                    trk.interaction_type = type;
                 }
             }
         }
@@ -436,14 +487,14 @@ __global__ void __launch_bounds__(256) propagate_group_kernel(DeviceProblem P, c
     }
     draws_total += (unsigned long long)rng.draws;
     __syncthreads();
-    for (int s = threadIdx.x; s < P.n_shells; s += blockDim.x) {
+    for (int s = threadIdx.x; s < P.n_shells; s += BLOCK) {
         if (lds_J[s] != 0.0) atomic_add_f64(&P.J[s], lds_J[s]);
         if (lds_nubar[s] != 0.0) atomic_add_f64(&P.nubar[s], lds_nubar[s]);
     }
     if (j == 0) {
         atomicAdd(&P.counters[0], cn.visits);
-        atomicAdd(&P.counters[1], cn.events);
-        atomicAdd(&P.counters[2], cn.macro);
+        atomicAdd(&P.counters[1], (unsigned long long)cn.events);
+        atomicAdd(&P.counters[2], (unsigned long long)cn.macro);
         atomicAdd(&P.counters[5], draws_total);
     }
 }

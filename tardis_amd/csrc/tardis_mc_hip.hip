@@ -113,8 +113,10 @@ struct TardisMcContext {
     long long chunk_packets = 8LL << 20;  // packets per seeded-state chunk (2496 B each) of the cooperative kernel
     // launch geometry
     int variant = 1;  // 0: lane-per-packet kernel; 1: cooperative 16-lanes-per-packet kernel (v-packets fall back to 0)
-    int blocks_per_cu = 8;
+    int blocks_per_cu = 16;
     int debug_flags = 0;
+    int group_size = 16;
+    int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
     // RCCL
     void *comm = nullptr;
     int rank = 0, world = 1;
@@ -422,6 +424,8 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "estimator_copies") { ctx->est_copies = std::max(1, std::min(8, (int)value)); ctx->est_valid = false; }
     else if (n == "vpacket_log_capacity") ctx->vlog_capacity = value;
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
+    else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
+    else if (n == "group_size") ctx->group_size = (value == 8) ? 8 : 16;
     else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
     else return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return TARDIS_MC_OK;
@@ -619,9 +623,20 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         const long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
         HIP_TRY(ctx, ctx->seeded_states.ensure((size_t)chunk * mc::MT_N * sizeof(uint32_t)));
         mc::DeviceProblem P = make_device_problem(ctx);
-        const size_t lds = (size_t)mc::GROUPS_PER_BLOCK * mc::MT_N * 4 + 2 * (size_t)ctx->n_shells * sizeof(double);
+        const int G = ctx->group_size == 8 ? 8 : 16;
+        const int block = 256;
+        const size_t lds = G == 8 ? mc::group_kernel_lds_bytes<8, 256>(ctx->n_shells) : mc::group_kernel_lds_bytes<16, 256>(ctx->n_shells);
         if (lds > 160 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
-        const int blocks_per_cu = std::max(1, std::min(ctx->blocks_per_cu, (int)((160 * 1024) / lds)));
+        const int blocks_per_cu = std::max(1, std::min(std::min(ctx->blocks_per_cu, 8), (int)((160 * 1024) / lds)));
+        using KernelFn = void (*)(mc::DeviceProblem, uint32_t *, long long, long long);
+        KernelFn k;
+        const bool full = c.enable_full_relativity != 0, trk = ctx->track;
+        const int occ = std::max(2, std::min(4, ctx->waves_per_simd));
+#define TMC_PICK(G_, B_, O_) (full ? (trk ? mc::propagate_group_kernel<true, true, G_, B_, O_> : mc::propagate_group_kernel<true, false, G_, B_, O_>) \
+                                   : (trk ? mc::propagate_group_kernel<false, true, G_, B_, O_> : mc::propagate_group_kernel<false, false, G_, B_, O_>))
+        if (G == 16) k = occ == 2 ? TMC_PICK(16, 256, 2) : (occ == 3 ? TMC_PICK(16, 256, 3) : TMC_PICK(16, 256, 4));
+        else k = occ == 2 ? TMC_PICK(8, 256, 2) : (occ == 3 ? TMC_PICK(8, 256, 3) : TMC_PICK(8, 256, 4));
+#undef TMC_PICK
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
         for (long long first = 0; first < ctx->n_packets; first += chunk) {
             const long long count = std::min(chunk, ctx->n_packets - first);
@@ -629,12 +644,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                                ctx->seeds.as<uint32_t>(), ctx->seeded_states.as<uint32_t>(), first, count);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), ctx->stream));
-            long long want_blocks = (count + mc::GROUPS_PER_BLOCK - 1) / mc::GROUPS_PER_BLOCK;
+            const int groups_per_block = block / G;
+            long long want_blocks = (count + groups_per_block - 1) / groups_per_block;
             int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)cus * blocks_per_cu));
-            auto k = c.enable_full_relativity
-                         ? (ctx->track ? mc::propagate_group_kernel<true, true> : mc::propagate_group_kernel<true, false>)
-                         : (ctx->track ? mc::propagate_group_kernel<false, true> : mc::propagate_group_kernel<false, false>);
-            hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, ctx->stream, P, ctx->seeded_states.as<uint32_t>(), first, count);
+            hipLaunchKernelGGL(k, dim3(blocks), dim3(block), lds, ctx->stream, P, ctx->seeded_states.as<uint32_t>(), first, count);
             HIP_TRY(ctx, hipGetLastError());
         }
     }

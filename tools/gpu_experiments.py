@@ -26,13 +26,15 @@ if "micro" in what:
             ms = eng.debug_microbench(which, n, iters, blocks)
             print(f"micro n={n * 8 / 1e6:8.1f} MB  {names[which]:46s} {ms:9.3f} ms  {nops / ms / 1e6:9.2f} Gop/s", flush=True)
 
-def run(P, flags=0, bpc=8, copies=1, track=1, kw=None, reps=2, variant=1):
+def run(P, flags=0, bpc=16, copies=1, track=1, kw=None, reps=2, variant=1, G=16, occ=4):
     kw = kw or dict(n_shells=20, n_lines=30000, line_interaction_type="downbranch")
     prob = run.cache.get((P, tuple(sorted(kw.items()))))
     if prob is None:
         prob = synthetic.make_problem(seed=1, n_packets=P, **kw)
         run.cache[(P, tuple(sorted(kw.items())))] = prob
     eng.set_option("variant", variant)
+    eng.set_option("group_size", G)
+    eng.set_option("waves_per_simd", occ)
     eng.set_option("debug_flags", flags)
     eng.set_option("blocks_per_cu", bpc)
     eng.set_option("estimator_copies", copies)
@@ -52,20 +54,24 @@ run.cache = {}
 
 if "ablate" in what:
     for P in (1_000_000, 10_000_000):
-        for variant in (0, 1):
-            for bpc in ((8,) if variant == 0 else (1, 2, 4)):
-                ms = run(P, 0, bpc, variant=variant)
-                print(f"ablate P={P:>9d} variant={variant} blocks/CU={bpc:2d} flags=0 track=1: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
+        ms = run(P, variant=0, bpc=8)
+        print(f"ablate P={P:>9d} variant=0: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
+        for G, occ in ((16, 4), (8, 4)):
+            ms = run(P, G=G, occ=occ)
+            print(f"ablate P={P:>9d} variant=1 G={G:2d} occ={occ}: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
         for flags in (1, 3):
-            ms = run(P, flags, 4, variant=1)
-            print(f"ablate P={P:>9d} variant=1 blocks/CU= 4 flags={flags} track=1: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
-        ms = run(P, 0, 4, track=0, variant=1)
-        print(f"ablate P={P:>9d} variant=1 blocks/CU= 4 flags=0 track=0: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
+            ms = run(P, flags)
+            print(f"ablate P={P:>9d} variant=1 G=16 occ=3 flags={flags}: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
+        ms = run(P, track=0)
+        print(f"ablate P={P:>9d} variant=1 G=16 occ=3 track=0: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
+        for bpc in (1, 2, 4, 6):
+            ms = run(P, bpc=bpc)
+            print(f"ablate P={P:>9d} variant=1 G=16 occ=3 blocks/CU={bpc}: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
 
 if "scale" in what:
     kw = dict(n_shells=20, n_lines=500000, line_interaction_type="macroatom")
     for P in (200_000, 2_000_000):
-        for variant in (0, 1):
-            ms = run(P, 0, 8 if variant == 0 else 4, kw=kw, reps=1, variant=variant)
-            print(f"config3-shape P={P} variant={variant}: {ms:9.2f} ms {P / ms / 1e3:8.3f} Mpkt/s", flush=True)
+        for G, occ in ((16, 4), (8, 4)):
+            ms = run(P, kw=kw, reps=1, G=G, occ=occ)
+            print(f"config3-shape P={P} variant=1 G={G} occ={occ}: {ms:9.2f} ms {P / ms / 1e3:8.3f} Mpkt/s", flush=True)
 eng.close()
