@@ -167,6 +167,9 @@ int tardis_mc_propagate(TardisMcContext *ctx);
 int tardis_mc_synchronize(TardisMcContext *ctx);
 /* Device time of the kernels launched by the last tardis_mc_propagate (HIP events on the ctx stream). */
 int tardis_mc_last_propagate_ms(TardisMcContext *ctx, double *out_ms);
+/* The same, split per kernel: total time of the MT19937 seeding launches and of the propagation launches of the last
+ * tardis_mc_propagate, and how many propagation launches there were (packet chunks). */
+int tardis_mc_last_kernel_times(TardisMcContext *ctx, double *out_seed_ms, double *out_propagate_ms, int *out_launches);
 /* Per-packet results of the resident packets + estimators (re-laid to [L,S]) to caller memory. */
 int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *result);
 
@@ -184,7 +187,7 @@ int tardis_mc_allreduce_estimators(TardisMcContext *ctx);
 
 /* ---- diagnostics: element-wise device arithmetic, used by the numerics parity tests ------------------
  * op: 0 x+y, 1 x*y, 2 x/y, 3 sqrt(x), 4 log(x) [engine's portable log], 5 exp(x), 6 x*y+x (un-fused),
- *     7 MT19937 doubles of seed (uint32)x[0] (n outputs), 8 floor(x). */
+ *     7 MT19937 doubles of seed (uint32)x[0] (n outputs), 8 floor(x), 9 x/y through the engine's exact 3-fma division. */
 int tardis_mc_debug_eval(TardisMcContext *ctx, int op, const double *x, const double *y, double *out, int64_t n);
 /* Memory-system micro-benchmarks used to size the kernels (design input): which = 0 random fp64 atomics (agent
  * scope), 1 same at workgroup scope in a per-XCD slice, 2/3 the same with 16 consecutive doubles per 16 lanes,

@@ -32,6 +32,7 @@ SYMBOLS = {
     "tardis_mc_propagate": (_i, [_vp]),
     "tardis_mc_synchronize": (_i, [_vp]),
     "tardis_mc_last_propagate_ms": (_i, [_vp, C.POINTER(C.c_double)]),
+    "tardis_mc_last_kernel_times": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "tardis_mc_get_results": (_i, [_vp, _vp]),
     "tardis_mc_run": (_i, [_vp] * 6),
     "tardis_mc_comm_get_unique_id": (_i, [_vp]),

@@ -146,52 +146,79 @@ struct GroupCounters { unsigned long long visits = 0; unsigned events = 0, macro
 
 // ---- one cooperative trace_packet (modes/homologous_rad_packet_transport.py:30-174)
 // All arguments / results are group-uniform except the lane index j.  Returns 0 or a negative error code.
+template <bool FULL, int G, bool FAST>
+__device__ __forceinline__ int sweep_lines(const GroupArgs &P, Packet &p, const int j, const double chi_cont,
+                                           const double tau_event, const double comov_nu, const double d_boundary,
+                                           int line, bool in_range, double nu_line, double tau_line,
+                                           double *__restrict__ jb, double *__restrict__ ed, double &distance, int &type,
+                                           GroupCounters &cn);
+
 template <bool FULL, int G>
-__device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet &p, GroupRng<G> &rng, const int j,
-                                                  const double chi_cont, double *__restrict__ jb, double *__restrict__ ed,
+__device__ __forceinline__ int trace_packet_group(const GroupArgs &P, Packet &p, GroupRng<G> &rng, const int j,
+                                                  const double chi_cont, const double r_inner, const double r_outer,
+                                                  const double dop, double *__restrict__ jb, double *__restrict__ ed,
                                                   double &distance, int &type, int &delta_shell, GroupCounters &cn)
+{
+    const int L = P.n_lines;
+    const int start = p.next_line_id;
+    // software pipeline: chunk c+1 is loaded while chunk c is evaluated; the first loads fly during the prologue
+    int line = start + j;
+    bool in_range = line < L;
+    double nu_line = in_range ? P.nu_line[(unsigned)line] : 0.0;
+    double tau_line = in_range ? P.tau_t[(unsigned)p.shell * (unsigned)L + (unsigned)line] : 0.0;
+
+    double d_boundary;
+    distance_boundary(p.r, p.mu, r_inner, r_outer, d_boundary, delta_shell);
+    const double tau_event = -mcm::log(rng.random(j));
+    const double comov_nu = p.nu * dop;
+    cn.events++;
+    // the 3-instruction exact division needs operands away from the exponent limits (always true for physical input)
+    const bool fast = mid_range(p.nu) && mid_range(chi_cont) && mid_range(tau_event) && mid_range(p.energy) &&
+                      mid_range(p.r) && mid_range(comov_nu) && mid_range(P.t_exp) && !(P.debug_flags & 4);
+    if (fast) return sweep_lines<FULL, G, true>(P, p, j, chi_cont, tau_event, comov_nu, d_boundary, line, in_range, nu_line,
+                                               tau_line, jb, ed, distance, type, cn);
+    return sweep_lines<FULL, G, false>(P, p, j, chi_cont, tau_event, comov_nu, d_boundary, line, in_range, nu_line, tau_line,
+                                       jb, ed, distance, type, cn);
+}
+
+// The line sweep of trace_packet (lines 100-172 of homologous_rad_packet_transport.py), G lines per step.
+template <bool FULL, int G, bool FAST>
+__device__ __forceinline__ int sweep_lines(const GroupArgs &P, Packet &p, const int j, const double chi_cont,
+                                           const double tau_event, const double comov_nu, const double d_boundary,
+                                           int line, bool in_range, double nu_line, double tau_line,
+                                           double *__restrict__ jb, double *__restrict__ ed, double &distance, int &type,
+                                           GroupCounters &cn)
 {
     const int L = P.n_lines;
     const double t = P.t_exp;
     const int start = p.next_line_id;
-    const double *__restrict__ tau_row = P.tau_t + (size_t)p.shell * L;
-    // software pipeline: chunk c+1 is loaded while chunk c is evaluated; the first loads fly during the prologue
-    int line = start + j;
-    bool in_range = line < L;
-    double nu_line = in_range ? P.nu_line[line] : 0.0;
-    double tau_line = in_range ? tau_row[line] : 0.0;
-
-    double d_boundary;
-    distance_boundary(p.r, p.mu, P.r_inner[p.shell], P.r_outer[p.shell], d_boundary, delta_shell);
-    const double tau_event = -mcm::log(rng.random(j));
-    const double velocity = p.r / t;
-    const double dop = doppler_factor<FULL>(velocity, p.mu);
-    const double comov_nu = p.nu * dop;
+    const unsigned row = (unsigned)p.shell * (unsigned)L;  // 32-bit element offset of this shell's row (S*L < 2^28)
+    const double *__restrict__ tau_t = P.tau_t;
     const double mur = p.mu * p.r;
-    const double tc = t * C_LIGHT;
-    double *__restrict__ jb_row = jb + (size_t)p.shell * L;
-    double *__restrict__ ed_row = ed + (size_t)p.shell * L;
+    const double tc = P.tc, rcp_tc = P.rcp_tc;
+    // reciprocals for the exact 3-instruction divisions of the sweep (the divisors are fixed during one trace)
+    const double rcp_nu = 1.0 / p.nu;
+    const double rcp_chi = 1.0 / chi_cont;
     const int last = L - 1;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);
     constexpr unsigned long long GMASK = (G == 16) ? 0xffffull : 0xffull;
     double tau_carry = 0.0;                      // tau_trace_line_combined before the first line of this chunk
-    double d_cont_carry = tau_event / chi_cont;  // distance_continuous in force at the first line of this chunk
-    cn.events++;
+    double d_cont_carry = exact_div<FAST>(tau_event, chi_cont, rcp_chi);  // distance_continuous in force at the first line of this chunk
 
     for (int cur0 = start; cur0 < L; cur0 += G) {
         // prefetch the next chunk
         const int nline = cur0 + G + j;
         const bool nin = nline < L;
-        const double nu_next = nin ? P.nu_line[nline] : 0.0;
-        const double tau_next = nin ? tau_row[nline] : 0.0;
+        const double nu_next = nin ? P.nu_line[(unsigned)nline] : 0.0;
+        const double tau_next = nin ? tau_t[row + (unsigned)nline] : 0.0;
 
         const double tau_incl = serial_prefix<G>(tau_carry, tau_line, j);
         const double tau_prev = group_shr1<G>(tau_carry, tau_incl, j);  // tau_trace_line_combined before this lane's line
-        const double d_cont = (j == 0) ? d_cont_carry : (tau_event - tau_prev) / chi_cont;
+        const double d_cont = (j == 0) ? d_cont_carry : exact_div<FAST>(tau_event - tau_prev, chi_cont, rcp_chi);
         // calculate_distance_line (calculate_distances.py:66-112), select form
         const bool is_last = line == last;
         const double nu_diff = comov_nu - nu_line;
-        const double q = nu_diff / p.nu;
+        const double q = exact_div<FAST>(nu_diff, p.nu, rcp_nu);
         const bool close = fabs(q) < CLOSE_LINE_THRESHOLD;
         const bool err = in_range && !is_last && !close && !(nu_diff >= 0);
         double d_far;
@@ -215,10 +242,10 @@ __device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet
         const bool visited = in_range && (j < first || (j == first && first_code == 3));
         if (visited && !(P.debug_flags & 1)) {
             double energy;
-            if (!FULL) energy = p.energy * (1.0 - ((d_trace + mur) / tc));
+            if (!FULL) energy = p.energy * (1.0 - exact_div<FAST>(d_trace + mur, tc, rcp_tc));
             else energy = p.energy;
-            atomic_add_f64(&jb_row[line], energy / p.nu);
-            atomic_add_f64(&ed_row[line], energy);
+            atomic_add_f64(&jb[row + (unsigned)line], exact_div<FAST>(energy, p.nu, rcp_nu));
+            atomic_add_f64(&ed[row + (unsigned)line], energy);
         }
         if (first < G) {
             cn.visits += (unsigned long long)(first + 1);
@@ -233,7 +260,7 @@ __device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet
         const int n_in = min(G, L - cur0);
         cn.visits += (unsigned long long)n_in;
         tau_carry = gbcast<G>(tau_incl, n_in - 1);
-        d_cont_carry = (tau_event - tau_carry) / chi_cont;
+        d_cont_carry = exact_div<FAST>(tau_event - tau_carry, chi_cont, rcp_chi);
         line = nline; in_range = nin; nu_line = nu_next; tau_line = tau_next;
     }
     // for-else (lines 157-172): the line list is exhausted; next_line_id is left untouched
@@ -245,7 +272,7 @@ __device__ __forceinline__ int trace_packet_group(const DeviceProblem &P, Packet
 // macro_atom_interaction (macro_atom.py:52-104): the transition block of the activated level is loaded G
 // probabilities at a time, accumulated in the reference's serial order, and a ballot finds the selected row.
 template <int G>
-__device__ __forceinline__ int macro_atom_group(const DeviceProblem &P, GroupRng<G> &rng, const int j, int level, int shell,
+__device__ __forceinline__ int macro_atom_group(const GroupArgs &P, GroupRng<G> &rng, const int j, int level, int shell,
                                                 int &out_line, GroupCounters &cn)
 {
     const double *__restrict__ prob_row = P.prob_t + (size_t)shell * P.n_trans;
@@ -286,11 +313,11 @@ __device__ __forceinline__ int macro_atom_group(const DeviceProblem &P, GroupRng
 template <int G, int BLOCK>
 __host__ __device__ constexpr size_t group_kernel_lds_bytes(int n_shells)
 {
-    return (size_t)(BLOCK / G) * sizeof(LdsTracker) + 2 * (size_t)n_shells * sizeof(double);
+    return (size_t)(BLOCK / G) * sizeof(LdsTracker) + 2 * (size_t)n_shells * sizeof(double);  // J, nu_bar
 }
 
 template <bool FULL, bool TRACK, int G, int BLOCK, int OCC>
-__global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(DeviceProblem P, uint32_t *__restrict__ seeded_states,
+__global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P, uint32_t *__restrict__ seeded_states,
                                                                 long long chunk_first, long long chunk_count)
 {
     constexpr int NGROUPS = BLOCK / G;
@@ -340,7 +367,10 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(DeviceProbl
                     if (exhausted) break;
                     unsigned long long base = 0;
                     if (lane == 0) base = atomicAdd(P.next_packet, (unsigned long long)PACKET_BATCH);
-                    base = __shfl(base, 0, 64);
+                    // wave-uniform control flow: lane 0 is the first active lane, so this makes the batch scalar
+                    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base);
+                    const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+                    base = ((unsigned long long)bhi << 32) | blo;
                     batch_next = min((long long)base, chunk_count);
                     batch_end = min((long long)base + PACKET_BATCH, chunk_count);
                     if (batch_next >= batch_end) { exhausted = true; break; }
@@ -359,7 +389,9 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(DeviceProbl
                     rng.attach(seeded_states + (size_t)pkt * MT_N);
                     rng.draws = 0;
                     const long long i = chunk_first + pkt;
-                    p.r = P.r0[i]; p.mu = P.mu0[i]; p.nu = P.nu0[i]; p.energy = P.e0[i];
+                    asm volatile("" ::: "memory");  // keep the cold-argument loads inside this (rare) branch
+                    const DeviceProblem *C = P.cold;
+                    p.r = C->r0[i]; p.mu = C->mu0[i]; p.nu = C->nu0[i]; p.energy = C->e0[i];
                     p.shell = 0; p.status = ST_IN_PROCESS;
                     if (TRACK && j == 0) {
                         const double nan = __builtin_nan("");
@@ -374,7 +406,7 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(DeviceProbl
                         double velocity = p.r / t;
                         double inv = inverse_doppler_factor<FULL>(velocity, p.mu);
                         if (FULL) {
-                            double beta = (p.r / t) / C_LIGHT;
+                            double beta = velocity / C_LIGHT;
                             p.nu *= inv; p.energy *= inv;
                             p.mu = (p.mu + beta) / (1 + beta * p.mu);
                         } else { p.nu *= inv; p.energy *= inv; }
@@ -403,7 +435,7 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(DeviceProbl
         if (FULL) chi_e *= dop;
         double distance;
         int type = 0, delta = 0;
-        int err = trace_packet_group<FULL, G>(P, p, rng, j, chi_e, jb, ed, distance, type, delta, cn);
+        int err = trace_packet_group<FULL, G>(P, p, rng, j, chi_e, P.r_inner[p.shell], P.r_outer[p.shell], dop, jb, ed, distance, type, delta, cn);
         if (!err) {
             // move_r_packet + update_estimators_bulk (packets/movement.py:31-76)
             double r = p.r;
@@ -463,39 +495,44 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(DeviceProbl
         if (err) {
             const long long i = chunk_first + pkt;
             if (j == 0) {
-                atomicMin(&P.first_error[0], i);
-                P.out_nu[i] = (double)err;
-                P.out_e[i] = -99.0;
+                asm volatile("" ::: "memory");
+                const DeviceProblem *C = P.cold;
+                atomicMin(&C->first_error[0], i);
+                C->out_nu[i] = (double)err;
+                C->out_e[i] = -99.0;
             }
             p.status = ST_EMITTED;
         } else if (p.status != ST_IN_PROCESS) {
             // set_packet_collection_output (modes/montecarlo_transport.py:70-90)
             const long long i = chunk_first + pkt;
             if (j == 0) {
-                P.out_nu[i] = p.nu;
-                P.out_e[i] = (p.status == ST_REABSORBED) ? -p.energy : p.energy;
+                asm volatile("" ::: "memory");  // keep the cold-argument loads inside this (rare) branch
+                const DeviceProblem *C = P.cold;
+                C->out_nu[i] = p.nu;
+                C->out_e[i] = (p.status == ST_REABSORBED) ? -p.energy : p.energy;
                 if (TRACK) {
-                    P.li_radius[i] = trk.radius; P.li_nu[i] = trk.nu; P.li_energy[i] = trk.energy;
-                    P.li_before_nu[i] = trk.before_nu; P.li_before_mu[i] = trk.before_mu; P.li_before_energy[i] = trk.before_energy;
-                    P.li_after_nu[i] = trk.after_nu; P.li_after_mu[i] = trk.after_mu; P.li_after_energy[i] = trk.after_energy;
-                    P.li_shell_id[i] = trk.shell_id; P.li_interaction_type[i] = trk.interaction_type;
-                    P.li_line_absorb_id[i] = trk.line_absorb_id; P.li_line_emit_id[i] = trk.line_emit_id;
-                    P.li_interactions_count[i] = trk.interactions_count;
+                    C->li_radius[i] = trk.radius; C->li_nu[i] = trk.nu; C->li_energy[i] = trk.energy;
+                    C->li_before_nu[i] = trk.before_nu; C->li_before_mu[i] = trk.before_mu; C->li_before_energy[i] = trk.before_energy;
+                    C->li_after_nu[i] = trk.after_nu; C->li_after_mu[i] = trk.after_mu; C->li_after_energy[i] = trk.after_energy;
+                    C->li_shell_id[i] = trk.shell_id; C->li_interaction_type[i] = trk.interaction_type;
+                    C->li_line_absorb_id[i] = trk.line_absorb_id; C->li_line_emit_id[i] = trk.line_emit_id;
+                    C->li_interactions_count[i] = trk.interactions_count;
                 }
             }
         }
     }
     draws_total += (unsigned long long)rng.draws;
     __syncthreads();
+    const DeviceProblem *C = P.cold;
     for (int s = threadIdx.x; s < P.n_shells; s += BLOCK) {
-        if (lds_J[s] != 0.0) atomic_add_f64(&P.J[s], lds_J[s]);
-        if (lds_nubar[s] != 0.0) atomic_add_f64(&P.nubar[s], lds_nubar[s]);
+        if (lds_J[s] != 0.0) atomic_add_f64(&C->J[s], lds_J[s]);
+        if (lds_nubar[s] != 0.0) atomic_add_f64(&C->nubar[s], lds_nubar[s]);
     }
     if (j == 0) {
-        atomicAdd(&P.counters[0], cn.visits);
-        atomicAdd(&P.counters[1], (unsigned long long)cn.events);
-        atomicAdd(&P.counters[2], (unsigned long long)cn.macro);
-        atomicAdd(&P.counters[5], draws_total);
+        atomicAdd(&C->counters[0], cn.visits);
+        atomicAdd(&C->counters[1], (unsigned long long)cn.events);
+        atomicAdd(&C->counters[2], (unsigned long long)cn.macro);
+        atomicAdd(&C->counters[5], draws_total);
     }
 }
 

@@ -79,6 +79,8 @@ struct TardisMcContext {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<hipEvent_t> ev_chunk;  // 3 per chunk of the cooperative path: before seed / after seed / after propagate
+    int chunks_timed = 0;
     bool timed = false;
     std::string err;
     hipDeviceProp_t prop{};
@@ -109,13 +111,14 @@ struct TardisMcContext {
     DevBuf vlog_count, vlog_packet, vlog_seq, vlog_nu, vlog_energy, vlog_mu, vlog_r;
     long long vlog_capacity = 0;
     // scratch
-    DevBuf rng_state, counters, first_error, next_packet, seeded_states;
-    long long chunk_packets = 8LL << 20;  // packets per seeded-state chunk (2496 B each) of the cooperative kernel
+    DevBuf rng_state, counters, first_error, next_packet, seeded_states, problem_dev;
+    mc::DeviceProblem problem_host{};
+    long long chunk_packets = 16LL << 20;  // packets per seeded-state chunk (2496 B each) of the cooperative kernel
     // launch geometry
     int variant = 1;  // 0: lane-per-packet kernel; 1: cooperative 16-lanes-per-packet kernel (v-packets fall back to 0)
     int blocks_per_cu = 16;
     int debug_flags = 0;
-    int group_size = 16;
+    int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
     int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
     // RCCL
     void *comm = nullptr;
@@ -194,6 +197,7 @@ __global__ void debug_eval_kernel(int op, const double *x, const double *y, doub
     case 5: r = mcm::exp(a); break;
     case 6: r = a * b + a; break;  // must NOT be contracted into an fma
     case 8: r = floor(a); break;
+    case 9: r = ((mc::mid_range(a) || a == 0.0) && mc::mid_range(b)) ? mc::exact_div<true>(a, b, 1.0 / b) : a / b; break;
     default: r = 0.0;
     }
     out[i] = r;
@@ -402,10 +406,11 @@ void tardis_mc_destroy(TardisMcContext *ctx)
                      &ctx->block_edge, &ctx->ttype, &ctx->dest, &ctx->tline, &ctx->staging, &ctx->est, &ctx->grid, &ctx->r0,
                      &ctx->mu0, &ctx->nu0, &ctx->e0, &ctx->seeds, &ctx->out_nu, &ctx->out_e, &ctx->vlog_count,
                      &ctx->vlog_packet, &ctx->vlog_seq, &ctx->vlog_nu, &ctx->vlog_energy, &ctx->vlog_mu, &ctx->vlog_r,
-                     &ctx->rng_state, &ctx->counters, &ctx->first_error, &ctx->next_packet, &ctx->seeded_states};
+                     &ctx->rng_state, &ctx->counters, &ctx->first_error, &ctx->next_packet, &ctx->seeded_states, &ctx->problem_dev};
     for (DevBuf *b : all) b->release();
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
+    for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -425,7 +430,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vpacket_log_capacity") ctx->vlog_capacity = value;
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
-    else if (n == "group_size") ctx->group_size = (value == 8) ? 8 : 16;
+    else if (n == "group_size") ctx->group_size = (value == 8) ? 8 : (value == 16 ? 16 : 0);
     else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
     else return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return TARDIS_MC_OK;
@@ -613,6 +618,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         const size_t lds = 2 * (size_t)ctx->n_shells * sizeof(double);
         if (lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        ctx->chunks_timed = 0;
         if (ctx->n_packets > 0) {
             if (c.enable_full_relativity) { if (vpk) launch_lane<true, true>(ctx, P, blocks, lds); else launch_lane<true, false>(ctx, P, blocks, lds); }
             else { if (vpk) launch_lane<false, true>(ctx, P, blocks, lds); else launch_lane<false, false>(ctx, P, blocks, lds); }
@@ -622,13 +628,30 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         // variant 1: cooperative kernel; MT19937 states are seeded per chunk by a lane-per-packet kernel
         const long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
         HIP_TRY(ctx, ctx->seeded_states.ensure((size_t)chunk * mc::MT_N * sizeof(uint32_t)));
-        mc::DeviceProblem P = make_device_problem(ctx);
-        const int G = ctx->group_size == 8 ? 8 : 16;
+        ctx->problem_host = make_device_problem(ctx);
+        const mc::DeviceProblem &F = ctx->problem_host;
+        HIP_TRY(ctx, ctx->problem_dev.ensure(sizeof(mc::DeviceProblem)));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->problem_dev.p, &ctx->problem_host, sizeof(mc::DeviceProblem), hipMemcpyHostToDevice, ctx->stream));
+        mc::GroupArgs P{};
+        P.cold = ctx->problem_dev.as<mc::DeviceProblem>();
+        P.n_shells = F.n_shells; P.n_lines = F.n_lines; P.n_trans = F.n_trans;
+        P.line_interaction_type = F.line_interaction_type; P.disable_line_scattering = F.disable_line_scattering;
+        P.debug_flags = F.debug_flags; P.n_est_copies = F.n_est_copies;
+        P.t_exp = F.t_exp; P.sigma_thomson = F.sigma_thomson;
+        P.tc = F.t_exp * mc::C_LIGHT; P.rcp_tc = 1.0 / P.tc;
+        if ((long long)ctx->n_shells * ctx->n_lines >= (1LL << 28) || (long long)ctx->n_shells * ctx->n_trans >= (1LL << 28))
+            return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells * n_lines exceeds the 32-bit table offsets of the cooperative kernel");
+        P.r_inner = F.r_inner; P.r_outer = F.r_outer; P.nu_line = F.nu_line; P.tau_t = F.tau_t; P.n_e = F.n_e; P.prob_t = F.prob_t;
+        P.line2level = F.line2level; P.block_edge = F.block_edge; P.ttype = F.ttype; P.dest = F.dest; P.tline = F.tline;
+        P.jblue_t = F.jblue_t; P.edot_t = F.edot_t; P.est_copy_stride = F.est_copy_stride;
+        P.next_packet = F.next_packet;
+        // group size: 8 lanes per packet pays off when the sweeps between events are short (sparse line lists)
+        const int G = ctx->group_size == 8 ? 8 : (ctx->group_size == 16 ? 16 : (ctx->n_lines <= 100000 ? 8 : 16));
         const int block = 256;
         const size_t lds = G == 8 ? mc::group_kernel_lds_bytes<8, 256>(ctx->n_shells) : mc::group_kernel_lds_bytes<16, 256>(ctx->n_shells);
         if (lds > 160 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
         const int blocks_per_cu = std::max(1, std::min(std::min(ctx->blocks_per_cu, 8), (int)((160 * 1024) / lds)));
-        using KernelFn = void (*)(mc::DeviceProblem, uint32_t *, long long, long long);
+        using KernelFn = void (*)(mc::GroupArgs, uint32_t *, long long, long long);
         KernelFn k;
         const bool full = c.enable_full_relativity != 0, trk = ctx->track;
         const int occ = std::max(2, std::min(4, ctx->waves_per_simd));
@@ -638,17 +661,28 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         else k = occ == 2 ? TMC_PICK(8, 256, 2) : (occ == 3 ? TMC_PICK(8, 256, 3) : TMC_PICK(8, 256, 4));
 #undef TMC_PICK
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        ctx->chunks_timed = 0;
         for (long long first = 0; first < ctx->n_packets; first += chunk) {
             const long long count = std::min(chunk, ctx->n_packets - first);
+            const int ci = ctx->chunks_timed;
+            while ((int)ctx->ev_chunk.size() < 3 * (ci + 1)) {
+                hipEvent_t e;
+                HIP_TRY(ctx, hipEventCreate(&e));
+                ctx->ev_chunk.push_back(e);
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3 * ci], ctx->stream));
             hipLaunchKernelGGL(mc::seed_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
                                ctx->seeds.as<uint32_t>(), ctx->seeded_states.as<uint32_t>(), first, count);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3 * ci + 1], ctx->stream));
             const int groups_per_block = block / G;
             long long want_blocks = (count + groups_per_block - 1) / groups_per_block;
             int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)cus * blocks_per_cu));
             hipLaunchKernelGGL(k, dim3(blocks), dim3(block), lds, ctx->stream, P, ctx->seeded_states.as<uint32_t>(), first, count);
             HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3 * ci + 2], ctx->stream));
+            ctx->chunks_timed = ci + 1;
         }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -673,6 +707,31 @@ int tardis_mc_last_propagate_ms(TardisMcContext *ctx, double *out_ms)
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     *out_ms = (double)ms;
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_last_kernel_times(TardisMcContext *ctx, double *out_seed_ms, double *out_propagate_ms, int *out_launches)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->timed) return fail(ctx, TARDIS_MC_ERR_STATE, "no propagate has been timed yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    double seed = 0.0, prop = 0.0;
+    if (ctx->chunks_timed == 0) {  // lane-per-packet variant: one launch, no seeding kernel
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+        prop = ms;
+    }
+    for (int ci = 0; ci < ctx->chunks_timed; ++ci) {
+        float a = 0.f, b = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev_chunk[3 * ci], ctx->ev_chunk[3 * ci + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev_chunk[3 * ci + 1], ctx->ev_chunk[3 * ci + 2]));
+        seed += a;
+        prop += b;
+    }
+    if (out_seed_ms) *out_seed_ms = seed;
+    if (out_propagate_ms) *out_propagate_ms = prop;
+    if (out_launches) *out_launches = ctx->chunks_timed ? ctx->chunks_timed : 1;
     return TARDIS_MC_OK;
 }
 
@@ -829,8 +888,10 @@ int tardis_mc_allreduce_estimators(TardisMcContext *ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = reduce_estimator_copies(ctx);
     if (rc) return rc;
-    if (ctx->world <= 1) return TARDIS_MC_OK;
-    if (!ctx->comm) return fail(ctx, TARDIS_MC_ERR_STATE, "tardis_mc_comm_init has not been called");
+    if (!ctx->comm) {
+        if (ctx->world <= 1) return TARDIS_MC_OK;  // single process, no communicator: nothing to reduce
+        return fail(ctx, TARDIS_MC_ERR_STATE, "tardis_mc_comm_init has not been called");
+    }
     EstLayout e = est_layout(ctx->est_S, ctx->est_L, ctx->est_G, ctx->est_copies);
     // ncclDouble = 8, ncclSum = 0; one in-place all-reduce over [J | nu_bar | v-hist | j_blue | Edotlu]
     int r = g_rccl.AllReduce(ctx->est.p, ctx->est.p, e.reduce_elems, 8, 0, ctx->comm, ctx->stream);

@@ -1,0 +1,42 @@
+"""Worker of tests/test_distributed_cpu.py: one rank of a world_size-2 gloo job (launched by torch.distributed.run).
+
+Exercises the host-side multi-GPU plumbing on CPU: environment rendezvous, packet sharding by index, disjoint
+per-packet output slices and the sum-all-reduce of the estimator arrays.  The per-shard transport itself is run by
+the CPU oracle here (test infrastructure) because no GPU exists in this container."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle  # noqa: E402
+from tardis_amd import distributed, synthetic  # noqa: E402
+
+
+def main():
+    out_path = sys.argv[1]
+    pg = distributed.init_from_env(backend="gloo")
+    assert pg.world_size == 2
+    prob = synthetic.make_problem(seed=31, n_packets=3001, n_shells=6, n_lines=900, line_interaction_type="macroatom")
+    pc = prob.packet_collection
+    lo, hi = distributed.shard_bounds(pc.number_of_packets, pg.rank, pg.world_size)
+    shard = pc.shard(pg.rank, pg.world_size)
+    assert shard.number_of_packets == hi - lo
+    r = oracle.run(shard, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
+                   prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE, write_outputs_in_place=True)
+    est = [r.j_estimator, r.nu_bar_estimator, r.j_blue_estimator, r.edotlu_estimator, r.v_packets_energy_hist]
+    pg.sum_arrays_(est)
+    # control-plane helpers
+    payload = pg.broadcast_bytes(b"x" * 128 if pg.rank == 0 else None, src=0)
+    assert payload == b"x" * 128
+    assert pg.max_float(float(pg.rank)) == 1.0
+    pg.barrier()
+    np.savez(out_path + f".rank{pg.rank}.npz", lo=lo, hi=hi, output_nus=pc.output_nus[lo:hi],
+             output_energies=pc.output_energies[lo:hi], j=est[0], nu_bar=est[1], j_blue=est[2], edotlu=est[3])
+    pg.destroy()
+
+
+if __name__ == "__main__":
+    main()

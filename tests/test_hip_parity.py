@@ -66,6 +66,27 @@ def test_device_arithmetic_is_ieee_and_unfused(engine, oracle):
     assert engine.debug_eval(4, np.array([0.0]))[0] == -np.inf
 
 
+def test_exact_division(engine):
+    """The kernels divide with a precomputed reciprocal + two fmas (Markstein); it must equal IEEE division bit for bit."""
+    rng = np.random.default_rng(11)
+    n = 2_000_000
+    def rand(n):
+        m = rng.integers(0, 2**52, n, dtype=np.uint64)
+        kind = rng.integers(0, 6, n)
+        m = np.where(kind == 1, np.uint64(2**52 - 1) - (m & np.uint64(0xff)), m)
+        m = np.where(kind == 2, m & np.uint64(0xff), m)
+        m = np.where(kind == 3, m & np.uint64(0xfffff00000000), m)
+        e = rng.integers(1023 - 100, 1023 + 100, n).astype(np.uint64)
+        return ((e << np.uint64(52)) | m).view(np.float64) * np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    a, b = rand(n), rand(n)
+    assert np.array_equal(engine.debug_eval(9, a, b), a / b)
+    # the ranges the kernels actually use, plus the guarded extremes (zero numerator, tiny / huge divisors)
+    a = np.concatenate([rng.random(1000) * 1e15, [0.0, 1.0, 1e-300, 1e300, 5.0, 3.0]])
+    b = np.concatenate([rng.random(1000) * 1e15 + 1.0, [3.0, 1e-310, 1e300, 1e-300, 0.0, np.inf]])
+    with np.errstate(divide="ignore"):
+        assert np.array_equal(engine.debug_eval(9, a, b), a / b)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 1963, 23111963, 2**32 - 2])
 def test_device_mt19937_matches_numpy_stream(engine, oracle, seed):
     got = engine.debug_eval(7, np.array([float(seed)]), n=1500)
@@ -200,3 +221,29 @@ def test_partition_invariance_and_determinism(engine):
     assert_allclose(jb, el.mean_intensity_blueward, rtol=EST_RTOL)
     assert visits == c_all["line_visits"]
     assert not np.any(full.output_energies == -99.0)
+
+
+def test_rccl_allreduce_single_rank(engine, oracle):
+    """The RCCL binding (dlopen, unique id, communicator, in-place all-reduce of the estimator block) on one rank:
+    the reduction over a 1-rank communicator must leave the estimators unchanged."""
+    prob = synthetic.make_problem(seed=21, n_packets=20_000, n_shells=10, n_lines=4000, line_interaction_type="macroatom")
+    from tardis_amd.engine import Engine
+    with Engine(0) as eng:
+        eng.comm_init(0, 1, Engine.comm_unique_id())
+        eng.set_geometry(prob.geometry, prob.time_explosion)
+        eng.set_opacity(prob.opacity_state)
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+        eng.set_packets(prob.packet_collection)
+        eng.reset_estimators()
+        eng.propagate()
+        eng.synchronize()
+        before = eng.get_results(track_last_interaction=False)
+        eng.allreduce_estimators()
+        eng.synchronize()
+        after = eng.get_results(track_last_interaction=False)
+    assert np.array_equal(before.j_estimator, after.j_estimator)
+    assert np.array_equal(before.j_blue_estimator, after.j_blue_estimator)
+    assert np.array_equal(before.edotlu_estimator, after.edotlu_estimator)
+    ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
+    assert np.array_equal(after.output_nus, ref.output_nus)
+    assert_allclose(after.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)

@@ -59,9 +59,9 @@ if "ablate" in what:
         for G, occ in ((16, 4), (8, 4)):
             ms = run(P, G=G, occ=occ)
             print(f"ablate P={P:>9d} variant=1 G={G:2d} occ={occ}: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
-        for flags in (1, 3):
-            ms = run(P, flags)
-            print(f"ablate P={P:>9d} variant=1 G=16 occ=3 flags={flags}: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
+        for flags in (1, 4):
+            ms = run(P, flags, G=8)
+            print(f"ablate P={P:>9d} variant=1 G=8 occ=4 flags={flags}: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
         ms = run(P, track=0)
         print(f"ablate P={P:>9d} variant=1 G=16 occ=3 track=0: {ms:9.2f} ms  {P / ms / 1e3:8.2f} Mpkt/s", flush=True)
         for bpc in (1, 2, 4, 6):

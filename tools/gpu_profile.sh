@@ -19,10 +19,11 @@ for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_LDS_ATOMIC" \
          "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCC_EA0_WRREQ_sum" \
          "TCC_EA0_RDREQ_sum TCC_EA0_ATOMIC_sum TCC_REQ_sum TCC_READ_sum" \
+         "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_64B_sum" \
          "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $c -d "$OUT/pmc_$i" -o pmc -- $BENCH > "$OUT/pmc_$i.log" 2>&1
 done
 cd "$ROOT"
-python tools/rocprof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+python tools/rocprof_summary.py "$OUT" "$OUT/pmc_traffic.json" > "$OUT/summary.txt" 2>&1
 find "$OUT" -name "*.db" -delete
