@@ -126,9 +126,11 @@ __device__ __forceinline__ double serial_prefix(double carry, double v, int j)
     double acc = head;
 #pragma unroll
     for (int s = 1; s < G; ++s) {
-        double prev = dpp_row_shr1(carry, acc);
+        // G == 16: lane 0 of the DPP row has no source and keeps `carry`.  G == 8: lane 0 of the second group of the row
+        // would read its row neighbour, so lane 0 is re-pinned explicitly (and the fill value is irrelevant).
+        double prev = dpp_row_shr1(G < 16 ? acc : carry, acc);
         acc = prev + v;
-        if (G < 16) acc = (j == 0) ? head : acc;  // an 8-lane group must not read across into its row neighbour
+        if (G < 16) acc = (j == 0) ? head : acc;
     }
     return acc;
 }
@@ -161,7 +163,8 @@ __device__ __forceinline__ int trace_packet_group(const GroupArgs &P, Packet &p,
 {
     const int L = P.n_lines;
     const int start = p.next_line_id;
-    // software pipeline: chunk c+1 is loaded while chunk c is evaluated; the first loads fly during the prologue
+    // software pipeline: chunk c+1 is loaded while chunk c is evaluated; the first loads fly during the prologue.
+    // (Aligning chunks to G-line memory segments was measured: fewer atomic/load requests but more chunk steps, net loss.)
     int line = start + j;
     bool in_range = line < L;
     double nu_line = in_range ? P.nu_line[(unsigned)line] : 0.0;
@@ -204,8 +207,24 @@ __device__ __forceinline__ int sweep_lines(const GroupArgs &P, Packet &p, const 
     constexpr unsigned long long GMASK = (G == 16) ? 0xffffull : 0xffull;
     double tau_carry = 0.0;                      // tau_trace_line_combined before the first line of this chunk
     double d_cont_carry = exact_div<FAST>(tau_event, chi_cont, rcp_chi);  // distance_continuous in force at the first line of this chunk
+    // The estimator atomics of a chunk are issued one chunk late, right after the wait for the next chunk's data: vector
+    // memory waits are in issue order (and loads mixed with atomics force vmcnt(0)), so atomics issued just before such a
+    // wait would put their full memory-side latency on the critical path; issued just after it they overlap a whole
+    // chunk of arithmetic.
+    bool pend_valid = false;
+    unsigned pend_idx = 0;
+    double pend_energy = 0.0;
+    auto flush_pending = [&]() {
+        if (pend_valid && !(P.debug_flags & 1)) {
+            atomic_add_f64(&jb[pend_idx], exact_div<FAST>(pend_energy, p.nu, rcp_nu));
+            atomic_add_f64(&ed[pend_idx], pend_energy);
+        }
+        pend_valid = false;
+    };
 
     for (int cur0 = start; cur0 < L; cur0 += G) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this chunk's prefetched data (and all older atomics) have landed
+        flush_pending();
         // prefetch the next chunk
         const int nline = cur0 + G + j;
         const bool nin = nline < L;
@@ -240,14 +259,12 @@ __device__ __forceinline__ int sweep_lines(const GroupArgs &P, Packet &p, const 
         const int first_code = gbcast<G>(code, first & (G - 1));
         // lines before the stopping one are passed (estimators updated); a LINE stop updates its own line too
         const bool visited = in_range && (j < first || (j == first && first_code == 3));
-        if (visited && !(P.debug_flags & 1)) {
-            double energy;
-            if (!FULL) energy = p.energy * (1.0 - exact_div<FAST>(d_trace + mur, tc, rcp_tc));
-            else energy = p.energy;
-            atomic_add_f64(&jb[row + (unsigned)line], exact_div<FAST>(energy, p.nu, rcp_nu));
-            atomic_add_f64(&ed[row + (unsigned)line], energy);
-        }
+        pend_valid = visited;
+        pend_idx = row + (unsigned)line;
+        if (!FULL) pend_energy = p.energy * (1.0 - exact_div<FAST>(d_trace + mur, tc, rcp_tc));
+        else pend_energy = p.energy;
         if (first < G) {
+            flush_pending();
             cn.visits += (unsigned long long)(first + 1);
             if (first_code == 4) return ERR_MONTECARLO;
             p.next_line_id = cur0 + first;
@@ -263,6 +280,7 @@ __device__ __forceinline__ int sweep_lines(const GroupArgs &P, Packet &p, const 
         d_cont_carry = exact_div<FAST>(tau_event - tau_carry, chi_cont, rcp_chi);
         line = nline; in_range = nin; nu_line = nu_next; tau_line = tau_next;
     }
+    flush_pending();
     // for-else (lines 157-172): the line list is exhausted; next_line_id is left untouched
     if (d_cont_carry < d_boundary) { distance = d_cont_carry; type = IT_ESCATTERING; }
     else { distance = d_boundary; type = IT_BOUNDARY; }
