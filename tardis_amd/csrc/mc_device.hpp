@@ -83,7 +83,10 @@ struct GroupArgs {
     double t_exp, sigma_thomson;
     double tc, rcp_tc;  // t_exp * c and its correctly rounded reciprocal (host-computed, kernel-uniform)
     const double *r_inner, *r_outer, *nu_line, *tau_t, *n_e, *prob_t;
-    const int *line2level, *block_edge, *ttype, *dest, *tline;
+    // macro atom, packed for one dependent load per jump: line_block[line] = {first, end} transition of the level the
+    // line activates; trans_rec[t] = {emission line id, transition type, first, end transition of the destination level}
+    const int2 *line_block;
+    const int4 *trans_rec;
     double *jblue_t, *edot_t;
     long long est_copy_stride;
     unsigned long long *next_packet;

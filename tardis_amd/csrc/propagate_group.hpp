@@ -288,30 +288,37 @@ __device__ __forceinline__ int sweep_lines(const GroupArgs &P, Packet &p, const 
 }
 
 // macro_atom_interaction (macro_atom.py:52-104): the transition block of the activated level is loaded G
-// probabilities at a time, accumulated in the reference's serial order, and a ballot finds the selected row.
+// probabilities at a time (together with the packed transition records), accumulated in the reference's serial
+// order, and a ballot finds the selected row.  The record carries the destination level's block bounds, so an
+// internal jump costs ONE dependent memory round trip instead of three (edge, probability, destination).
 template <int G>
-__device__ __forceinline__ int macro_atom_group(const GroupArgs &P, GroupRng<G> &rng, const int j, int level, int shell,
+__device__ __forceinline__ int macro_atom_group(const GroupArgs &P, GroupRng<G> &rng, const int j, int b0, int b1, int shell,
                                                 int &out_line, GroupCounters &cn)
 {
-    const double *__restrict__ prob_row = P.prob_t + (size_t)shell * P.n_trans;
+    const unsigned row = (unsigned)shell * (unsigned)P.n_trans;
+    const double *__restrict__ prob_t = P.prob_t;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);
     constexpr unsigned long long GMASK = (G == 16) ? 0xffffull : 0xffull;
-    int ttype = 0, tid = -1;
-    while (ttype >= 0) {
+    for (;;) {
         const double event = rng.random(j);
-        const int b0 = P.block_edge[level], b1 = P.block_edge[level + 1];
         double carry = 0.0;
+        int ttype = 0;
         bool found = false;
         for (int base = b0; base < b1; base += G) {
             const int k = base + j;
             const bool in = k < b1;
-            const double pr = in ? prob_row[k] : 0.0;
+            const double pr = in ? prob_t[row + (unsigned)k] : 0.0;
+            int4 rec = make_int4(0, 0, 0, 0);
+            if (in) rec = P.trans_rec[(unsigned)k];
             const double acc = serial_prefix<G>(carry, pr, j);
             const unsigned hit = (unsigned)((__ballot(in && acc > event) >> gshift) & GMASK);
             if (hit) {
                 const int f = __builtin_ctz(hit);
-                tid = base + f;
                 cn.macro += (unsigned)(f + 1);
+                out_line = gbcast<G>(rec.x, f);
+                ttype = gbcast<G>(rec.y, f);
+                b0 = gbcast<G>(rec.z, f);
+                b1 = gbcast<G>(rec.w, f);
                 found = true;
                 break;
             }
@@ -320,12 +327,8 @@ __device__ __forceinline__ int macro_atom_group(const GroupArgs &P, GroupRng<G> 
             carry = gbcast<G>(acc, n_in - 1);
         }
         if (!found) return ERR_MACRO_ATOM;
-        level = P.dest[tid];
-        ttype = P.ttype[tid];
+        if (ttype < 0) return ttype == -1 ? 0 : ERR_UNSUPPORTED;
     }
-    if (ttype != -1) return ERR_UNSUPPORTED;
-    out_line = P.tline[tid];
-    return 0;
 }
 
 template <int G, int BLOCK>
@@ -489,7 +492,10 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
                 if (type == IT_LINE) {
                     int emit = p.next_line_id;
                     if (P.line_interaction_type != 0)
-                        err = macro_atom_group<G>(P, rng, j, P.line2level[p.next_line_id], p.shell, emit, cn);
+                    {
+                        const int2 blk = P.line_block[(unsigned)p.next_line_id];
+                        err = macro_atom_group<G>(P, rng, j, blk.x, blk.y, p.shell, emit, cn);
+                    }
                     if (!err) {  // line_emission (interaction_events.py:227-258); its inverse Doppler factor == inv_new
                         p.nu = P.nu_line[emit] * inv_new;
                         p.next_line_id = emit + 1;

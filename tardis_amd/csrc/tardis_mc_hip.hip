@@ -92,7 +92,7 @@ struct TardisMcContext {
     DevBuf r_inner, r_outer;
     // opacity
     int n_lines = 0, n_trans = 0, n_levels = 0;
-    DevBuf nu_line, tau_t, n_e, prob_t, line2level, block_edge, ttype, dest, tline, staging;
+    DevBuf nu_line, tau_t, n_e, prob_t, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec;
     // estimators: one allocation [J | nubar | vhist | pad | jblue copy0 | edot copy0 | jblue copy1.. | edot copy1..]
     DevBuf est;
     size_t est_S = 0, est_L = 0, est_G = 0;
@@ -403,7 +403,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     DevBuf *all[] = {&ctx->r_inner, &ctx->r_outer, &ctx->nu_line, &ctx->tau_t, &ctx->n_e, &ctx->prob_t, &ctx->line2level,
-                     &ctx->block_edge, &ctx->ttype, &ctx->dest, &ctx->tline, &ctx->staging, &ctx->est, &ctx->grid, &ctx->r0,
+                     &ctx->block_edge, &ctx->ttype, &ctx->dest, &ctx->tline, &ctx->staging, &ctx->line_block, &ctx->trans_rec, &ctx->est, &ctx->grid, &ctx->r0,
                      &ctx->mu0, &ctx->nu0, &ctx->e0, &ctx->seeds, &ctx->out_nu, &ctx->out_e, &ctx->vlog_count,
                      &ctx->vlog_packet, &ctx->vlog_seq, &ctx->vlog_nu, &ctx->vlog_energy, &ctx->vlog_mu, &ctx->vlog_r,
                      &ctx->rng_state, &ctx->counters, &ctx->first_error, &ctx->next_packet, &ctx->seeded_states, &ctx->problem_dev};
@@ -504,6 +504,28 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     if ((rc = upload_i32(ctx, ctx->ttype, macro ? o->transition_type : &zero64, macro ? T : 1, tmp))) return rc;
     if ((rc = upload_i32(ctx, ctx->dest, macro ? o->destination_level_id : &zero64, macro ? T : 1, tmp))) return rc;
     if ((rc = upload_i32(ctx, ctx->tline, macro ? o->transition_line_id : &zero64, macro ? T : 1, tmp))) return rc;
+    {   // packed macro-atom tables of the cooperative kernel
+        std::vector<int> lb(2 * (macro ? L : 1), 0), rec(4 * (macro ? T : 1), 0);
+        if (macro) {
+            for (size_t i = 0; i < L; ++i) {
+                const int64_t lvl = o->line2macro_level_upper[i];
+                lb[2 * i] = (int)o->macro_block_edge_index[lvl];
+                lb[2 * i + 1] = (int)o->macro_block_edge_index[lvl + 1];
+            }
+            for (size_t t = 0; t < T; ++t) {
+                rec[4 * t] = (int)o->transition_line_id[t];
+                rec[4 * t + 1] = (int)o->transition_type[t];
+                if (o->transition_type[t] >= 0) {
+                    const int64_t lvl = o->destination_level_id[t];
+                    rec[4 * t + 2] = (int)o->macro_block_edge_index[lvl];
+                    rec[4 * t + 3] = (int)o->macro_block_edge_index[lvl + 1];
+                }
+            }
+        }
+        if ((rc = upload(ctx, ctx->line_block, lb.data(), lb.size()))) return rc;
+        if ((rc = upload(ctx, ctx->trans_rec, rec.data(), rec.size()))) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (ctx->have_geometry && (int)S != ctx->n_shells)
         return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "opacity has %zu shells, geometry has %d", S, ctx->n_shells);
     ctx->n_lines = (int)L; ctx->n_trans = (int)T; ctx->n_levels = macro ? (int)E - 1 : 0;
@@ -642,7 +664,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         if ((long long)ctx->n_shells * ctx->n_lines >= (1LL << 28) || (long long)ctx->n_shells * ctx->n_trans >= (1LL << 28))
             return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells * n_lines exceeds the 32-bit table offsets of the cooperative kernel");
         P.r_inner = F.r_inner; P.r_outer = F.r_outer; P.nu_line = F.nu_line; P.tau_t = F.tau_t; P.n_e = F.n_e; P.prob_t = F.prob_t;
-        P.line2level = F.line2level; P.block_edge = F.block_edge; P.ttype = F.ttype; P.dest = F.dest; P.tline = F.tline;
+        P.line_block = ctx->line_block.as<int2>(); P.trans_rec = ctx->trans_rec.as<int4>();
         P.jblue_t = F.jblue_t; P.edot_t = F.edot_t; P.est_copy_stride = F.est_copy_stride;
         P.next_packet = F.next_packet;
         // group size: 8 lanes per packet pays off when the sweeps between events are short (sparse line lists)

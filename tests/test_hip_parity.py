@@ -247,3 +247,39 @@ def test_rccl_allreduce_single_rank(engine, oracle):
     ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
     assert np.array_equal(after.output_nus, ref.output_nus)
     assert_allclose(after.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+
+
+def test_baseline_config2_full_size(engine, oracle):
+    """BASELINE.json configs[1] at full size (1e7 packets, 20 shells, 3e4 lines, downbranch) through size-independent
+    properties: every packet terminates, the work counters add up, chunked launches (4 chunks) reproduce the single
+    launch bit for bit per packet and to 1e-11 in the estimators, and a 1e5-packet sample equals the oracle."""
+    from tardis_amd import spectrum
+    prob = synthetic.make_problem(seed=1, **synthetic.BASELINE_CONFIGS[2])
+    pc = prob.packet_collection
+    P = pc.number_of_packets
+    assert P == 10_000_000
+    engine.set_option("chunk_packets", 16 << 20)
+    hist, vt, eb, el, _, c1 = run_hip(engine, prob, track=False)
+    nus, ens = pc.output_nus.copy(), pc.output_energies.copy()
+    assert c1["packets"] == P and c1["events"] >= P and c1["line_visits"] >= c1["events"]
+    assert not np.any(ens == -99.0) and np.all(np.isfinite(nus)) and np.all(nus > 0)
+    emitted = ens >= 0
+    assert 0.2 < emitted.mean() < 0.6
+    # chunked launches
+    engine.set_option("chunk_packets", 3_000_000)
+    _, _, eb2, el2, _, c2 = run_hip(engine, prob, track=False)
+    engine.set_option("chunk_packets", 16 << 20)
+    assert np.array_equal(pc.output_nus, nus) and np.array_equal(pc.output_energies, ens)
+    assert c1 == c2
+    assert_allclose(eb2.mean_intensity_total, eb.mean_intensity_total, rtol=EST_RTOL)
+    assert_allclose(el2.mean_intensity_blueward, el.mean_intensity_blueward, rtol=EST_RTOL)
+    # oracle on the first 1e5 packets (per-packet results do not depend on batching)
+    sub = pc.shard(0, 100)
+    ref = oracle.run(sub, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
+                     prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE, n_threads=oracle.max_threads(),
+                     track_last_interaction=False)
+    n = sub.number_of_packets
+    assert np.array_equal(nus[:n], ref.output_nus) and np.array_equal(ens[:n], ref.output_energies)
+    a = spectrum.emitted_luminosity_histogram(nus[:n], ens[:n], pc.time_of_simulation, prob.spectrum_frequency_grid)
+    b = spectrum.emitted_luminosity_histogram(ref.output_nus, ref.output_energies, pc.time_of_simulation, prob.spectrum_frequency_grid)
+    assert spectrum.relative_l2(a, b) == 0.0
