@@ -90,6 +90,15 @@ struct GroupArgs {
     double *jblue_t, *edot_t;
     long long est_copy_stride;
     unsigned long long *next_packet;
+    // v-packets (only read by the VPK instantiations)
+    long long n_vpackets;
+    double survival_probability, tau_russian, spawn_start, spawn_end, grid0, grid_last, delta_nu;
+    double *vhist;
+    // frequency-bucket index of the line list: key(nu) = (bits(nu) >> bucket_shift) - bucket_kmin is monotone in nu;
+    // bucket_first[k] = index of the first line (descending list) whose key is <= k
+    const int *bucket_first;
+    int bucket_shift, bucket_n;
+    long long bucket_kmin;
 };
 
 struct Packet {

@@ -59,16 +59,17 @@ __global__ void __launch_bounds__(256) seed_states_kernel(const uint32_t *__rest
 template <int G>
 struct GroupRng {
     uint32_t *st;    // this packet's 624-word state (global)
-    uint32_t blk;    // word (fresh - G + j) of the current generation (untempered), valid once fresh > 0
-    int idx;         // next output word (group-uniform, even)
-    int fresh;       // words [0, fresh) of the current generation are regenerated (group-uniform, multiple of G)
+    uint32_t blk;    // lane j holds word (generated - G + j) of the stream (untempered)
+    int consumed;    // stream words consumed since attach (group-uniform, even)
+    int generated;   // stream words regenerated since attach (group-uniform, multiple of G, >= consumed)
+    int cpos, gpos;  // consumed % 624, generated % 624
     int draws;
 
-    __device__ __forceinline__ void attach(uint32_t *state) { st = state; idx = 0; fresh = 0; blk = 0; }
+    __device__ __forceinline__ void attach(uint32_t *state) { st = state; consumed = generated = cpos = gpos = 0; blk = 0; }
     __device__ __forceinline__ void regenerate(int j)
-    {   // words [fresh, fresh+G) of the next generation; 624 = 39*16 = 78*8
-        if (fresh == MT_N) fresh = 0;
-        const int k = fresh + j;
+    {   // next G words of the stream, in place at [gpos, gpos+G); 624 = 39*16 = 78*8.  Never call with
+        // generated + G > consumed + 624 (it would overwrite unconsumed words).
+        const int k = gpos + j;
         const int k1 = (k + 1 == MT_N) ? 0 : k + 1;
         const int km = (k + 397 >= MT_N) ? k + 397 - MT_N : k + 397;
         // make this wave's earlier stores to the state visible to these loads (same wave: waitcnt only)
@@ -81,20 +82,49 @@ struct GroupRng {
         st[k] = v;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         blk = v;
-        fresh += G;
+        generated += G;
+        gpos = (gpos + G == MT_N) ? 0 : gpos + G;
     }
-    __device__ __forceinline__ double random(int j)
+    __device__ static __forceinline__ double to_double(uint32_t a, uint32_t b)
     {
-        if (idx == MT_N) idx = 0;
-        if (idx == fresh || (fresh == MT_N && idx == 0)) regenerate(j);
-        const int w = idx & (G - 1);
-        uint32_t a = (uint32_t)__shfl((int)blk, w, G), b = (uint32_t)__shfl((int)blk, w + 1, G);
-        idx += 2;
         a ^= a >> 11; a ^= (a << 7) & 0x9d2c5680u; a ^= (a << 15) & 0xefc60000u; a ^= a >> 18;
         b ^= b >> 11; b ^= (b << 7) & 0x9d2c5680u; b ^= (b << 15) & 0xefc60000u; b ^= b >> 18;
         a >>= 5; b >>= 6;
-        ++draws;
         return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+    __device__ __forceinline__ void advance(int words)
+    {
+        consumed += words;
+        cpos += words;
+        if (cpos >= MT_N) cpos -= MT_N;
+    }
+    __device__ __forceinline__ double random(int j)
+    {
+        if (consumed == generated) regenerate(j);
+        uint32_t a, b;
+        if (generated - consumed <= G) {  // the pair is in the register-resident block
+            const int w = cpos & (G - 1);
+            a = (uint32_t)__shfl((int)blk, w, G);
+            b = (uint32_t)__shfl((int)blk, w + 1, G);
+        } else {  // regenerated ahead (v-packet volleys peek): read it back from the state
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            a = st[cpos];
+            b = st[cpos + 1];
+        }
+        advance(2);
+        ++draws;
+        return to_double(a, b);
+    }
+    // ---- look-ahead used by the v-packet volleys: the n-th double after the current position, per lane
+    __device__ __forceinline__ void ensure_ahead(int words, int j)
+    {   // group-cooperative: make words [consumed, consumed + words) available (words <= 624 - 2 G)
+        while (generated - consumed < words) regenerate(j);
+    }
+    __device__ __forceinline__ double peek(int n) const
+    {
+        int w = cpos + 2 * n;
+        if (w >= MT_N) w -= MT_N;
+        return to_double(st[w], st[w + 1]);
     }
 };
 
@@ -331,13 +361,229 @@ __device__ __forceinline__ int macro_atom_group(const GroupArgs &P, GroupRng<G> 
     }
 }
 
+// ---- v-packets (packets/virtual_packet.py:82-386).  Inside a volley every LANE of the group traces one v-packet (the
+// per-v-packet work is a serial sum over lines, which the reference's accumulation order does not let us split), i.e.
+// up to G v-packets of one volley advance together.  The n_v mu-draws and the Russian-roulette draws all come from the
+// parent packet's stream in sequence; lane i therefore reads its draws at the stream position it would have IF no
+// earlier v-packet of the round played roulette.  After the round the first lane that did consume a roulette draw
+// invalidates the lanes after it, which are simply re-traced in the next round from the corrected stream position.
+struct VpDraws {  // draws of ONE v-packet: position `first` (in doubles after the group's current stream position)
+    int first, used, limit;
+    bool overflow;
+};
+
+template <bool FULL, int G>
+__device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &rng, VpDraws &dr, double r, double mu, double nu,
+                                        double &energy, int shell, int next_line, double &tau_out, unsigned &vvisits)
+{
+    const int L = P.n_lines;
+    const double t = P.t_exp;
+    double tau = 0.0;
+    int status = ST_IN_PROCESS;
+    for (;;) {
+        // trace_vpacket_within_shell (:82-175).  The reference walks the lines one by one until the first one whose
+        // resonance distance is >= the boundary distance and adds up their tau in that order.  The stopping predicate is
+        // monotone along the (descending) line list, so the stopping index is located through the frequency-bucket
+        // index and then pinned with the reference's own predicate; the tau sum keeps the reference's order.
+        double d_boundary;
+        int delta;
+        distance_boundary(r, mu, P.r_inner[shell], P.r_outer[shell], d_boundary, delta);
+        const double chi_e = P.n_e[shell] * P.sigma_thomson;
+        const double velocity = r / t;
+        const double dop = doppler_factor<FULL>(velocity, mu);
+        const double comov_nu = nu * dop;
+        double chi_cont = chi_e;
+        if (FULL) chi_cont *= dop;
+        double tau_shell = chi_cont * d_boundary;
+        const unsigned row = (unsigned)shell * (unsigned)L;
+        const int start = next_line;
+        if (start < L) {
+            double d_line;
+            // the reference evaluates line `start` first and raises there if it lies blueward of the packet
+            if (!distance_line<FULL>(nu, r, mu, comov_nu, start == L - 1, P.nu_line[(unsigned)start], t, d_line)) return ERR_MONTECARLO;
+            int e = start;
+            if (!(d_boundary <= d_line)) {
+                // approximate stopping frequency: nu_line ~ comov_nu - d_boundary nu / (c t)
+                const double nu_thr = comov_nu - d_boundary * P.rcp_tc * nu;
+                long long kk = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
+                kk = kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
+                e = max(P.bucket_first[kk], start + 1);
+                if (e > L - 1) e = L - 1;
+                // forward to the first line that stops, then back while the previous one stops as well
+                for (;;) {
+                    if (!distance_line<FULL>(nu, r, mu, comov_nu, e == L - 1, P.nu_line[(unsigned)e], t, d_line)) return ERR_MONTECARLO;
+                    if (d_boundary <= d_line || e == L - 1) break;
+                    ++e;
+                }
+                bool stops = d_boundary <= d_line;
+                while (e > start + 1) {
+                    double d_prev;
+                    if (!distance_line<FULL>(nu, r, mu, comov_nu, false, P.nu_line[(unsigned)(e - 1)], t, d_prev)) return ERR_MONTECARLO;
+                    if (!(d_boundary <= d_prev)) break;
+                    --e;
+                    stops = true;
+                }
+                if (!stops) e = L;  // (only with a NaN/huge boundary distance: the reference then sums every line)
+            }
+            // serial-order sum of tau over [start, e): loads are independent of the adds, issue them four at a time
+            const double *__restrict__ trow = P.tau_t + row;
+            int k = start;
+            const int e_sum = min(e, L);
+            for (; k + 4 <= e_sum; k += 4) {
+                const double t0 = trow[(unsigned)k], t1 = trow[(unsigned)k + 1], t2 = trow[(unsigned)k + 2], t3 = trow[(unsigned)k + 3];
+                tau_shell += t0; tau_shell += t1; tau_shell += t2; tau_shell += t3;
+            }
+            for (; k < e_sum; ++k) tau_shell += trow[(unsigned)k];
+            vvisits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
+            next_line = e;
+        }
+        // trace_vpacket (:179-244)
+        tau += tau_shell;
+        cross_shell(shell, status, delta, P.n_shells);
+        if (tau > P.tau_russian) {
+            double ev = 0.0;
+            if (dr.used < dr.limit) ev = rng.peek(dr.first + dr.used); else dr.overflow = true;
+            dr.used++;
+            if (ev > P.survival_probability) {
+                energy = 0.0;
+                status = ST_EMITTED;
+            } else {
+                energy = energy / P.survival_probability * mcm::exp(-tau);
+                tau = 0.0;
+            }
+        }
+        const double new_r = sqrt(r * r + d_boundary * d_boundary + 2.0 * r * d_boundary * mu);
+        mu = (mu * r + d_boundary) / new_r;
+        r = new_r;
+        if (status == ST_EMITTED) break;
+    }
+    tau_out = tau;
+    return 0;
+}
+
+template <bool FULL, int G>
+__device__ __forceinline__ int volley_group(const GroupArgs &P, const Packet &p, GroupRng<G> &rng, const int j, long long packet_index,
+                                            int &vseq, unsigned &pred_bits, unsigned &vvisits, unsigned &vcount, unsigned long long &vtraced)
+{   // trace_vpacket_volley (:248-386)
+    if (p.nu < P.spawn_start || p.nu > P.spawn_end) return 0;
+    const int n_v = (int)P.n_vpackets;
+    if (n_v == 0) return 0;
+    const double t = P.t_exp;
+    double mu_min, beta_inner = 0.0;
+    bool on_inner;
+    const double r_in0 = P.r_inner[0];
+    if (p.r > r_in0) {
+        double r_inner_over_r = r_in0 / p.r;
+        mu_min = -sqrt(1 - r_inner_over_r * r_inner_over_r);
+        on_inner = false;
+        if (FULL) mu_min = aberration_lf_to_cmf(p.r, t, mu_min);
+    } else {
+        on_inner = true;
+        mu_min = 0.0;
+        if (FULL) {
+            const double inv_c = 1 / C_LIGHT;
+            double inv_t = 1 / t;
+            beta_inner = r_in0 * inv_t * inv_c;
+        }
+    }
+    const double mu_bin = (1.0 - mu_min) / (double)n_v;
+    const double r_velocity = p.r / t;
+    const double r_dop = doppler_factor<FULL>(r_velocity, p.mu);
+    const int gshift = (threadIdx.x & 63) & ~(G - 1);
+    constexpr unsigned long long GMASK = (G == 16) ? 0xffffull : 0xffull;
+    constexpr int ROULETTE_SLACK = 8;  // spare draws available to a round beyond one mu + one roulette draw per v-packet
+    const DeviceProblem *C = P.cold;
+
+    int done = 0;    // v-packets of this volley finalised so far (group-uniform)
+    int err_out = 0;
+    while (done < n_v) {
+        const int n_round = min(G, n_v - done);
+        rng.ensure_ahead(2 * (2 * n_round + ROULETTE_SLACK), j);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the peeks below read what regenerate() stored
+        const int i = done + j;  // this lane's v-packet
+        const bool active = j < n_round;
+        // Predicted roulette draws consumed by the v-packets of this round that precede lane j.  v-packet i of every volley
+        // is launched into the same mu bin, so whether it played roulette the last time it was traced (previous volley of
+        // this packet, or a discarded speculative trace of this volley) predicts whether it will now: bit i of pred_bits.
+        const unsigned round_bits = (pred_bits >> done) & ((1u << j) - 1u);  // v-packets done .. i-1
+        const int extra_before = __popc(round_bits);
+        const int pred_self = (int)((pred_bits >> i) & 1u);
+        int err = 0;
+        VpDraws dr;
+        dr.first = j + extra_before; dr.used = 0; dr.overflow = false;
+        dr.limit = (2 * n_round + ROULETTE_SLACK) - dr.first - 1;
+        double v_nu = 0.0, v_energy = 0.0, v_mu0 = 0.0;
+        unsigned my_visits = 0;
+        if (active) {
+            const double xi = rng.peek(dr.first);
+            dr.first += 1;  // roulette draws follow the mu draw
+            double v_mu = mu_min + (double)i * mu_bin + xi * mu_bin;
+            double weight;
+            if (on_inner) {
+                if (!FULL) weight = 2 * v_mu / (double)n_v;
+                else weight = 2 * (v_mu + beta_inner) / (2 * beta_inner + 1) / (double)n_v;
+            } else
+                weight = (1 - mu_min) / (double)(2 * n_v);
+            if (FULL) v_mu = aberration_cmf_to_lf(p.r, t, v_mu);
+            v_mu0 = v_mu;  // the log records the (aberrated) launch direction (virtual_packet.py:337-340,375)
+            const double v_dop = doppler_factor<FULL>(r_velocity, v_mu);
+            const double ratio = r_dop / v_dop;
+            v_nu = p.nu * ratio;
+            v_energy = p.energy * weight * ratio;
+            double tau_v;
+            err = vp_trace<FULL, G>(P, rng, dr, p.r, v_mu, v_nu, v_energy, p.shell, p.next_line_id, tau_v, my_visits);
+            if (!err) v_energy *= mcm::exp(-tau_v);
+            if (dr.overflow) err = ERR_UNSUPPORTED;
+        }
+        // the first lane whose draw consumption differs from the prediction (or that failed) ends the validity of the round:
+        // it started from the right stream position itself, the lanes after it did not
+        const unsigned bad = (unsigned)((__ballot(active && (dr.used != pred_self || err != 0)) >> gshift) & GMASK);
+        const int f = bad ? __builtin_ctz(bad) : G;
+        const int n_ok = min(n_round, f + 1);
+        const int used_f = gbcast<G>(dr.used, f & (G - 1));
+        const int extra_f = gbcast<G>(extra_before, f & (G - 1));
+        const int err_f = gbcast<G>(err, f & (G - 1));
+        if (f < G && err_f) { err_out = err_f; break; }
+        vtraced += my_visits;
+        if (j < n_ok) {
+            ++vcount;
+            vvisits += my_visits;
+            // add_vpacket_collection_to_histogram (modes/montecarlo_transport.py:166-195)
+            if (!(v_nu < P.grid0 || v_nu > P.grid_last)) {
+                long long idx = (long long)floor((v_nu - P.grid0) / P.delta_nu);
+                atomic_add_f64(&P.vhist[idx], v_energy);
+            }
+            if (C->vlog_count) {
+                unsigned long long slot = atomicAdd(C->vlog_count, 1ull);
+                if ((long long)slot < C->vlog_capacity) {
+                    C->vlog_packet[slot] = packet_index; C->vlog_seq[slot] = vseq + j;
+                    C->vlog_nu[slot] = v_nu; C->vlog_energy[slot] = v_energy; C->vlog_mu[slot] = v_mu0; C->vlog_r[slot] = p.r;
+                }
+            }
+        }
+        // stream words consumed by the committed v-packets: one mu draw each + their roulette draws
+        int extra_used;
+        if (f < n_round) extra_used = extra_f + used_f;                                            // lanes < f matched the prediction
+        else extra_used = __popc((pred_bits >> done) & ((n_round >= 32) ? 0xffffffffu : ((1u << n_round) - 1u)));  // all matched
+        // learn from every trace of this round, valid or not (same mu bin => same optical depth to first order)
+        const unsigned obs = (unsigned)((__ballot(active && dr.used > 0) >> gshift) & GMASK);
+        const unsigned seen = (n_round >= 32) ? 0xffffffffu : ((1u << n_round) - 1u);
+        pred_bits = (pred_bits & ~(seen << done)) | (obs << done);
+        vseq += n_ok;
+        done += n_ok;
+        rng.advance(2 * (n_ok + extra_used));
+        rng.draws += n_ok + extra_used;
+    }
+    return err_out;
+}
+
 template <int G, int BLOCK>
 __host__ __device__ constexpr size_t group_kernel_lds_bytes(int n_shells)
 {
     return (size_t)(BLOCK / G) * sizeof(LdsTracker) + 2 * (size_t)n_shells * sizeof(double);  // J, nu_bar
 }
 
-template <bool FULL, bool TRACK, int G, int BLOCK, int OCC>
+template <bool FULL, bool TRACK, int G, int BLOCK, int OCC, bool VPK>
 __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P, uint32_t *__restrict__ seeded_states,
                                                                 long long chunk_first, long long chunk_count)
 {
@@ -363,6 +609,11 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
     LdsTracker &trk = lds_trk[g];
     GroupCounters cn;
     unsigned long long draws_total = 0;
+    unsigned vvisits = 0, vcount = 0;  // per-lane v-packet work counters
+    unsigned long long vtraced = 0;    // line visits of all v-packet traces incl. discarded speculative ones
+    int vseq = 0;                      // v-packets emitted so far by this group's packet (group-uniform)
+    unsigned pred_bits = 0;            // roulette predictor of the v-packet volleys (see volley_group)
+    bool want_volley = false;          // this group's packet is paused until the wave's next volley phase
 
     // wave-level packet batches: PACKET_BATCH indices are reserved per global atomic and handed to the wave's groups.
     // batch_next / batch_end / exhausted are wave-uniform and only modified in wave-uniform control flow.
@@ -443,11 +694,39 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
                         if (lo == P.n_lines) lo -= 1;
                         p.next_line_id = lo;
                     }
+                    if (VPK) {  // volley at launch (classic/packet_propagation.py:109-118), run in the next volley phase
+                        vseq = 0;
+                        pred_bits = 0;
+                        want_volley = true;
+                    }
                 }
             }
         }
         if (__ballot(!done) == 0ull) break;
-        if (done) continue;
+        if (VPK) {
+            // Volley phase.  A volley keeps n_v lanes of ONE group busy for a long time, so it only runs when every group
+            // of the wave that still has a packet is waiting for one: groups that reach an interaction early pause (cheap:
+            // the others are stepping through boundary crossings) instead of making the others idle through a volley.
+            const bool live = !done && p.status == ST_IN_PROCESS;
+            const unsigned long long live_mask = __ballot(live), want_mask = __ballot(live && want_volley);
+            if (want_mask != 0ull && want_mask == live_mask) {
+                if (live && want_volley) {
+                    const int verr = volley_group<FULL, G>(P, p, rng, j, chunk_first + pkt, vseq, pred_bits, vvisits, vcount, vtraced);
+                    want_volley = false;
+                    if (verr) {
+                        if (j == 0) {
+                            const DeviceProblem *C2 = P.cold;
+                            atomicMin(&C2->first_error[0], chunk_first + pkt);
+                            C2->out_nu[chunk_first + pkt] = (double)verr;
+                            C2->out_e[chunk_first + pkt] = -99.0;
+                        }
+                        p.status = ST_EMITTED;
+                    }
+                }
+            }
+            if (want_volley) continue;  // paused until the wave's volley phase
+        }
+        if (done || p.status != ST_IN_PROCESS) continue;  // (a volley may have failed: fetch another packet)
 
         // ---------------------------------------------------------------- one event of this group's packet
         double velocity = p.r / t;
@@ -514,6 +793,8 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
                     trk.radius = p.r; trk.nu = p.nu; trk.energy = p.energy; trk.shell_id = p.shell;
                     trk.interaction_type = type;
                 }
+                // volley after a line or electron-scattering interaction (classic/packet_propagation.py:201-244)
+                if (VPK && !err) want_volley = true;
             }
         }
         if (err) {
@@ -557,6 +838,11 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
         atomicAdd(&C->counters[1], (unsigned long long)cn.events);
         atomicAdd(&C->counters[2], (unsigned long long)cn.macro);
         atomicAdd(&C->counters[5], draws_total);
+    }
+    if (VPK) {
+        if (vvisits) atomicAdd(&C->counters[3], (unsigned long long)vvisits);
+        if (vcount) atomicAdd(&C->counters[4], (unsigned long long)vcount);
+        if (vtraced) atomicAdd(&C->counters[7], vtraced);
     }
 }
 

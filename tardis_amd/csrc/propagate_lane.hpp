@@ -382,7 +382,6 @@ __device__ int propagate_one(const DeviceProblem &P, long long i, Rng &rng, doub
                 trk.radius = p.r; trk.nu = p.nu; trk.energy = p.energy; trk.shell_id = p.shell;
                 trk.interaction_type = IT_LINE;
             }
-            if (VPK) { if ((err = trace_vpacket_volley<FULL>(P, p, rng, i, vseq, cn))) return err; }
         } else {  // IT_ESCATTERING
             if (TRACK) {
                 trk.before_mu = p.mu; trk.before_nu = p.nu; trk.before_energy = p.energy;
@@ -395,8 +394,10 @@ __device__ int propagate_one(const DeviceProblem &P, long long i, Rng &rng, doub
                 trk.radius = p.r; trk.nu = p.nu; trk.energy = p.energy; trk.shell_id = p.shell;
                 trk.interaction_type = IT_ESCATTERING;
             }
-            if (VPK) { if ((err = trace_vpacket_volley<FULL>(P, p, rng, i, vseq, cn))) return err; }
         }
+        // one shared call site for the volley after a line or electron-scattering interaction: lanes of both kinds trace
+        // their v-packets together instead of serialising two inlined copies of the volley
+        if (VPK && type != IT_BOUNDARY) { if ((err = trace_vpacket_volley<FULL>(P, p, rng, i, vseq, cn))) return err; }
     }
     // set_packet_collection_output (modes/montecarlo_transport.py:70-90)
     P.out_nu[i] = p.nu;

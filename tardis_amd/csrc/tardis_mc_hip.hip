@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -92,7 +93,9 @@ struct TardisMcContext {
     DevBuf r_inner, r_outer;
     // opacity
     int n_lines = 0, n_trans = 0, n_levels = 0;
-    DevBuf nu_line, tau_t, n_e, prob_t, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec;
+    DevBuf nu_line, tau_t, n_e, prob_t, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec, bucket_first;
+    int bucket_shift = 0, bucket_n = 0;
+    long long bucket_kmin = 0;
     // estimators: one allocation [J | nubar | vhist | pad | jblue copy0 | edot copy0 | jblue copy1.. | edot copy1..]
     DevBuf est;
     size_t est_S = 0, est_L = 0, est_G = 0;
@@ -403,7 +406,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
     DevBuf *all[] = {&ctx->r_inner, &ctx->r_outer, &ctx->nu_line, &ctx->tau_t, &ctx->n_e, &ctx->prob_t, &ctx->line2level,
-                     &ctx->block_edge, &ctx->ttype, &ctx->dest, &ctx->tline, &ctx->staging, &ctx->line_block, &ctx->trans_rec, &ctx->est, &ctx->grid, &ctx->r0,
+                     &ctx->block_edge, &ctx->ttype, &ctx->dest, &ctx->tline, &ctx->staging, &ctx->line_block, &ctx->trans_rec, &ctx->bucket_first, &ctx->est, &ctx->grid, &ctx->r0,
                      &ctx->mu0, &ctx->nu0, &ctx->e0, &ctx->seeds, &ctx->out_nu, &ctx->out_e, &ctx->vlog_count,
                      &ctx->vlog_packet, &ctx->vlog_seq, &ctx->vlog_nu, &ctx->vlog_energy, &ctx->vlog_mu, &ctx->vlog_r,
                      &ctx->rng_state, &ctx->counters, &ctx->first_error, &ctx->next_packet, &ctx->seeded_states, &ctx->problem_dev};
@@ -526,6 +529,30 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         if ((rc = upload(ctx, ctx->trans_rec, rec.data(), rec.size()))) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    {   // frequency-bucket index over the (descending) line list, ~2-4 lines per bucket
+        auto bits = [](double x) { uint64_t u; memcpy(&u, &x, 8); return u; };
+        const double nu_hi = o->line_list_nu[0], nu_lo = o->line_list_nu[L - 1];
+        int mbits = 4;
+        if (nu_lo > 0 && nu_hi >= nu_lo) {
+            const double binades = std::max(1.0, std::log2(nu_hi / nu_lo));
+            const double per_binade = (double)L / binades;
+            while (mbits < 20 && per_binade / (double)(1 << mbits) > 3.0) ++mbits;
+        }
+        const int shift = 52 - mbits;
+        const long long kmin = (long long)(bits(nu_lo > 0 ? nu_lo : 1.0) >> shift), kmax = (long long)(bits(nu_hi > 0 ? nu_hi : 1.0) >> shift);
+        const long long K = std::max<long long>(1, kmax - kmin + 1);
+        if (K > (1LL << 26)) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "line list frequency range too wide for the bucket index");
+        std::vector<int> first((size_t)K, 0);
+        // first[k] = smallest i with key(nu_line[i]) <= kmin + k; keys are non-increasing along the list
+        size_t i = 0;
+        for (long long k = K - 1; k >= 0; --k) {
+            while (i < L && (long long)(bits(o->line_list_nu[i]) >> shift) - kmin > k) ++i;
+            first[(size_t)k] = (int)i;
+        }
+        if ((rc = upload(ctx, ctx->bucket_first, first.data(), first.size()))) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->bucket_shift = shift; ctx->bucket_n = (int)K; ctx->bucket_kmin = kmin;
+    }
     if (ctx->have_geometry && (int)S != ctx->n_shells)
         return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "opacity has %zu shells, geometry has %d", S, ctx->n_shells);
     ctx->n_lines = (int)L; ctx->n_trans = (int)T; ctx->n_levels = macro ? (int)E - 1 : 0;
@@ -629,7 +656,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     HIP_TRY(ctx, ctx->next_packet.ensure(sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // init_err lives on this stack frame
-    const bool cooperative = ctx->variant == 1 && !vpk;
+    const bool cooperative = ctx->variant == 1 && (!vpk || c.number_of_vpackets <= 32);  // the volley predictor is a 32-bit mask
 
     if (!cooperative) {
         // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment
@@ -667,8 +694,13 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         P.line_block = ctx->line_block.as<int2>(); P.trans_rec = ctx->trans_rec.as<int4>();
         P.jblue_t = F.jblue_t; P.edot_t = F.edot_t; P.est_copy_stride = F.est_copy_stride;
         P.next_packet = F.next_packet;
+        P.n_vpackets = F.n_vpackets; P.survival_probability = F.survival_probability; P.tau_russian = F.tau_russian;
+        P.spawn_start = F.spawn_start; P.spawn_end = F.spawn_end; P.grid0 = F.grid0; P.grid_last = F.grid_last;
+        P.delta_nu = F.delta_nu; P.vhist = F.vhist;
+        P.bucket_first = ctx->bucket_first.as<int>(); P.bucket_shift = ctx->bucket_shift; P.bucket_n = ctx->bucket_n;
+        P.bucket_kmin = ctx->bucket_kmin;
         // group size: 8 lanes per packet pays off when the sweeps between events are short (sparse line lists)
-        const int G = ctx->group_size == 8 ? 8 : (ctx->group_size == 16 ? 16 : (ctx->n_lines <= 100000 ? 8 : 16));
+        const int G = ctx->group_size == 8 ? 8 : (ctx->group_size == 16 ? 16 : ((ctx->n_lines <= 100000 && !vpk) ? 8 : 16));
         const int block = 256;
         const size_t lds = G == 8 ? mc::group_kernel_lds_bytes<8, 256>(ctx->n_shells) : mc::group_kernel_lds_bytes<16, 256>(ctx->n_shells);
         if (lds > 160 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
@@ -676,12 +708,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         using KernelFn = void (*)(mc::GroupArgs, uint32_t *, long long, long long);
         KernelFn k;
         const bool full = c.enable_full_relativity != 0, trk = ctx->track;
-        const int occ = std::max(2, std::min(4, ctx->waves_per_simd));
-#define TMC_PICK(G_, B_, O_) (full ? (trk ? mc::propagate_group_kernel<true, true, G_, B_, O_> : mc::propagate_group_kernel<true, false, G_, B_, O_>) \
-                                   : (trk ? mc::propagate_group_kernel<false, true, G_, B_, O_> : mc::propagate_group_kernel<false, false, G_, B_, O_>))
-        if (G == 16) k = occ == 2 ? TMC_PICK(16, 256, 2) : (occ == 3 ? TMC_PICK(16, 256, 3) : TMC_PICK(16, 256, 4));
-        else k = occ == 2 ? TMC_PICK(8, 256, 2) : (occ == 3 ? TMC_PICK(8, 256, 3) : TMC_PICK(8, 256, 4));
-#undef TMC_PICK
+#define TMC_PICK2(G_, V_) (full ? (trk ? mc::propagate_group_kernel<true, true, G_, 256, 4, V_> : mc::propagate_group_kernel<true, false, G_, 256, 4, V_>) \
+                                : (trk ? mc::propagate_group_kernel<false, true, G_, 256, 4, V_> : mc::propagate_group_kernel<false, false, G_, 256, 4, V_>))
+        if (G == 16) k = vpk ? TMC_PICK2(16, true) : TMC_PICK2(16, false);
+        else k = vpk ? TMC_PICK2(8, true) : TMC_PICK2(8, false);
+#undef TMC_PICK2
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
         ctx->chunks_timed = 0;
         for (long long first = 0; first < ctx->n_packets; first += chunk) {

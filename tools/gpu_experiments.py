@@ -74,4 +74,24 @@ if "scale" in what:
         for G, occ in ((16, 4), (8, 4)):
             ms = run(P, kw=kw, reps=1, G=G, occ=occ)
             print(f"config3-shape P={P} variant=1 G={G} occ={occ}: {ms:9.2f} ms {P / ms / 1e3:8.3f} Mpkt/s", flush=True)
+pass
+
+if "vpk" in what:
+    eng2 = Engine(0)
+    for kw, P in ((dict(n_shells=20, n_lines=30000, line_interaction_type="downbranch", n_vpackets=10), 2_000_000),
+                  (dict(n_shells=20, n_lines=30000, line_interaction_type="macroatom", n_vpackets=3), 200_000)):
+        prob = synthetic.make_problem(seed=1, n_packets=P, **kw)
+        eng2.set_geometry(prob.geometry, prob.time_explosion)
+        eng2.set_opacity(prob.opacity_state)
+        eng2.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+        eng2.set_packets(prob.packet_collection)
+        for _ in range(2):
+            eng2.reset_estimators(); eng2.propagate(); eng2.synchronize()
+        ms = eng2.last_propagate_ms()
+        res = eng2.get_results(track_last_interaction=False, want_line_estimators=False)
+        c = res.counters
+        print(f"vpackets {kw['line_interaction_type']} n_v={kw['n_vpackets']} P={P}: {ms:9.2f} ms {P / ms / 1e3:8.3f} Mpkt/s; per packet: "
+              f"vpackets={c['vpackets'] / P:.1f} vp_line_visits={c['vpacket_line_visits'] / P:.0f} line_visits={c['line_visits'] / P:.0f}; "
+              f"{c['vpacket_line_visits'] / ms / 1e6:.2f} G vp-line-visits/s; traced/committed={c['reserved'] / max(c['vpacket_line_visits'], 1):.2f}", flush=True)
+    eng2.close()
 eng.close()
