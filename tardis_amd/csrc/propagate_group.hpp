@@ -686,10 +686,18 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
                     {   // initialize_line_id (packets/radiative_packet.py:96-110)
                         double velocity = p.r / t;
                         double comov_nu = p.nu * doppler_factor<FULL>(velocity, p.mu);
-                        int lo = 0, hi = P.n_lines;
-                        while (lo < hi) {
-                            int mid = (lo + hi) >> 1;
-                            if (P.nu_line[mid] >= comov_nu) lo = mid + 1; else hi = mid;
+                        // number of lines with nu_line >= comov_nu (searchsorted on the reversed list); the bucket index
+                        // narrows it to the few lines sharing comov_nu's key, which are compared exactly
+                        int lo;
+                        {
+                            const long long kk = (long long)((unsigned long long)__double_as_longlong(comov_nu > 0.0 ? comov_nu : 0.0) >> P.bucket_shift) - P.bucket_kmin;
+                            if (kk >= P.bucket_n) lo = 0;
+                            else if (kk < 0) lo = P.n_lines;
+                            else {
+                                lo = P.bucket_first[kk];
+                                const int hi = kk > 0 ? P.bucket_first[kk - 1] : P.n_lines;
+                                while (lo < hi && P.nu_line[(unsigned)lo] >= comov_nu) ++lo;
+                            }
                         }
                         if (lo == P.n_lines) lo -= 1;
                         p.next_line_id = lo;

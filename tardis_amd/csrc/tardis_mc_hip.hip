@@ -96,6 +96,7 @@ struct TardisMcContext {
     DevBuf nu_line, tau_t, n_e, prob_t, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec, bucket_first;
     int bucket_shift = 0, bucket_n = 0;
     long long bucket_kmin = 0;
+    bool lines_sorted = true;  // line_list_nu strictly usable by the index-based kernels (non-increasing, positive)
     // estimators: one allocation [J | nubar | vhist | pad | jblue copy0 | edot copy0 | jblue copy1.. | edot copy1..]
     DevBuf est;
     size_t est_S = 0, est_L = 0, est_G = 0;
@@ -529,6 +530,10 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         if ((rc = upload(ctx, ctx->trans_rec, rec.data(), rec.size()))) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    ctx->lines_sorted = true;
+    for (size_t i = 0; i < L; ++i)
+        if (!(o->line_list_nu[i] > 0.0) || (i > 0 && !(o->line_list_nu[i] <= o->line_list_nu[i - 1]))) { ctx->lines_sorted = false; break; }
+    if (ctx->lines_sorted)
     {   // frequency-bucket index over the (descending) line list, ~2-4 lines per bucket
         auto bits = [](double x) { uint64_t u; memcpy(&u, &x, 8); return u; };
         const double nu_hi = o->line_list_nu[0], nu_lo = o->line_list_nu[L - 1];
@@ -656,7 +661,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     HIP_TRY(ctx, ctx->next_packet.ensure(sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // init_err lives on this stack frame
-    const bool cooperative = ctx->variant == 1 && (!vpk || c.number_of_vpackets <= 32);  // the volley predictor is a 32-bit mask
+    // the cooperative kernel relies on a sorted line list (bucket index, monotone stopping predicate); anything else --
+    // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
+    const bool cooperative = ctx->variant == 1 && ctx->lines_sorted && (!vpk || c.number_of_vpackets <= 32);
 
     if (!cooperative) {
         // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment
