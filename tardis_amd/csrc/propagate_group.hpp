@@ -145,6 +145,13 @@ __device__ __forceinline__ double dpp_row_shr1(double first, double v)
     int hi = __builtin_amdgcn_update_dpp(__double2hiint(first), __double2hiint(v), 0x111, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// the same with +0.0 shifted into lane 0 of the row (bound_ctrl): no fill operand to set up
+__device__ __forceinline__ double dpp_row_shr1_zero(double v)
+{
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x111, 0xf, 0xf, true);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x111, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 
 // ((carry + v0) + v1) + ... + vj for lane j: the reference's sequential accumulation order, evaluated exactly.
 // acc <- shr1(acc) + v repeated G-1 times: after step s lanes 0..s hold their final value and recomputing a final
@@ -154,13 +161,19 @@ __device__ __forceinline__ double serial_prefix(double carry, double v, int j)
 {
     const double head = carry + v;  // value of the group's first lane
     double acc = head;
+    if (G == 16) {
+        // lane 0 adds its head to the +0.0 shifted in (exact), every other lane adds its own v to its left neighbour
+        const double addend = (j == 0) ? head : v;
 #pragma unroll
-    for (int s = 1; s < G; ++s) {
-        // G == 16: lane 0 of the DPP row has no source and keeps `carry`.  G == 8: lane 0 of the second group of the row
-        // would read its row neighbour, so lane 0 is re-pinned explicitly (and the fill value is irrelevant).
-        double prev = dpp_row_shr1(G < 16 ? acc : carry, acc);
-        acc = prev + v;
-        if (G < 16) acc = (j == 0) ? head : acc;
+        for (int s = 1; s < G; ++s) acc = dpp_row_shr1_zero(acc) + addend;
+    } else {
+#pragma unroll
+        for (int s = 1; s < G; ++s) {
+            // an 8-lane group shares its DPP row with a neighbour group: lane 0 is re-pinned explicitly
+            double prev = dpp_row_shr1(acc, acc);
+            acc = prev + v;
+            acc = (j == 0) ? head : acc;
+        }
     }
     return acc;
 }
