@@ -146,7 +146,9 @@ def main():
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        default_workload = (args.config == 2 and args.packets is None and args.lines is None and args.shells is None
+                            and args.mode is None and args.vpackets is None and not args.no_tracking)
+        if default_workload and os.path.exists(pmc_path):  # the PMC passes were collected on the default workload
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:
