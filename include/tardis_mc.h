@@ -173,6 +173,41 @@ int tardis_mc_last_kernel_times(TardisMcContext *ctx, double *out_seed_ms, doubl
 /* Per-packet results of the resident packets + estimators (re-laid to [L,S]) to caller memory. */
 int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *result);
 
+/* ---- producer next to the path: black-body packet source on the device --------------------------------
+ * BlackBodySimpleSource.create_packets (transport/montecarlo/packet_source/base.py:195-253, black_body.py:140-222) with
+ * NumPy's Generator(PCG64) streams reproduced by jump-ahead: fills the resident packet inputs (radii, nus, mus,
+ * energies, seeds) of packets [first, first+count) of a global n_total-packet draw, as if set_packets had been called
+ * with that slice of the host-sampled collection.  pcg_state = {state_hi, state_lo, inc_hi, inc_lo} of the PCG64
+ * bit generator (numpy: default_rng(seed).bit_generator.state, or tardis_mc_pcg64_seed below); max_seed_val is
+ * BasePacketSource.MAX_SEED_VAL (base.py:25, 2^32-1); l_array is cumsum(arange(1, l_samples)**-4) (black_body.py:174).
+ * packet_seeds are bit-exact; mus bit-exact; nus within 1 ulp of a host run (the reference's log is numexpr's). */
+int tardis_mc_pcg64_seed(uint64_t seed, uint64_t out_state[4]);  /* SeedSequence(seed) -> PCG64 state; host only */
+int tardis_mc_create_blackbody_packets(TardisMcContext *ctx, int64_t n_total, int64_t first, int64_t count, double radius,
+                                       double temperature, const uint64_t pcg_state[4], uint32_t max_seed_val,
+                                       const double *l_array, int64_t n_l);
+/* download the resident packet inputs (any pointer may be NULL) */
+int tardis_mc_get_packets(TardisMcContext *ctx, double *initial_radii, double *initial_nus, double *initial_mus,
+                          double *initial_energies, int64_t *packet_seeds);
+
+/* ---- consumer next to the path: real-packet spectrum + filtered luminosities on the device -------------
+ * From the per-packet outputs resident after tardis_mc_propagate: histograms of emitted / reabsorbed packet luminosity
+ * (+/- output_energy / time_of_simulation) over the spectrum_frequency_grid passed to tardis_mc_set_config, with
+ * numpy.histogram's edge rules (tardis/spectrum/base.py:140-159), and the luminosity sums over
+ * luminosity_nu_start < nu < luminosity_nu_end (tardis/spectrum/luminosity.py:5-30).  Histograms have n_grid-1 bins. */
+int tardis_mc_packet_spectrum(TardisMcContext *ctx, double time_of_simulation, double luminosity_nu_start,
+                              double luminosity_nu_end, double *emitted_luminosity_hist, double *reabsorbed_luminosity_hist,
+                              double *out_emitted_luminosity, double *out_reabsorbed_luminosity);
+
+/* ---- consumer next to the path: radiation-field update from the resident estimators -------------------
+ * MCRadiationFieldPropertiesSolver.solve (transport/montecarlo/estimators/mc_rad_field_solver.py:37-144):
+ *   t_radiative[s] = C_T nu_bar[s] / J[s];  dilution_factor[s] = J[s] / (4 sigma_sb t_rad^4 time_of_simulation volume[s]);
+ *   j_blues[l][s] = j_blue_estimator[l][s] c t_exp / (4 pi time_of_simulation volume[s]), cells with a zero estimator get
+ *   w_epsilon * W[s] B_nu(nu_l, t_rad[s]), and with detailed_optical_window lines outside 2500-10000 A get W B_nu.
+ * Runs after tardis_mc_propagate (and, multi-GPU, after tardis_mc_allreduce_estimators).  volume: [n_shells] cm^3.
+ * Outputs (host, any may be NULL): t_radiative[n_shells], dilution_factor[n_shells], j_blues[n_lines*n_shells] line-major. */
+int tardis_mc_radiation_field(TardisMcContext *ctx, double time_of_simulation, const double *volume, double w_epsilon,
+                              int detailed_optical_window, double *t_radiative, double *dilution_factor, double *j_blues);
+
 /* ---- one-shot API: the reference boundary in one call ---------------------------------------------- */
 int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const TardisMcGeometry *geometry,
                   const TardisMcOpacity *opacity, const TardisMcConfig *config, TardisMcResult *result);

@@ -20,6 +20,8 @@
 #include "mc_device.hpp"
 #include "propagate_lane.hpp"
 #include "propagate_group.hpp"
+#include "propagate_wave.hpp"
+#include "packet_source.hpp"
 
 namespace {
 
@@ -234,6 +236,85 @@ __global__ void microbench_kernel(int which, double *table, long long n, int ite
         else acc += table[idx];
     }
     if (acc == 123.456) sink[0] = acc;
+}
+
+// ---- real-packet spectrum and filtered luminosities from the resident per-packet outputs
+// (SpectrumSolver.montecarlo_emitted/reabsorbed_luminosity, tardis/spectrum/base.py:140-159: np.histogram with the
+//  spectrum_frequency_grid edges, weights = +/- output_energies / time_of_simulation split on output_energies >= 0
+//  (montecarlo_transport_state.py:130-160); calculate_filtered_luminosity, tardis/spectrum/luminosity.py:5-30)
+__global__ void spectrum_kernel(const double *__restrict__ out_nu, const double *__restrict__ out_e, long long n,
+                                const double *__restrict__ edges, int n_edges, double t_sim, double nu_start, double nu_end,
+                                double *hist_emitted, double *hist_reabsorbed, double *lum /* [2] */)
+{
+    const int B = n_edges - 1;
+    const double e0 = edges[0], eN = edges[B];
+    const double inv_delta = (double)B / (eN - e0);
+    double lum_e = 0.0, lum_r = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double e = out_e[i], nu = out_nu[i];
+        const bool emitted = e >= 0;
+        const double l = emitted ? (e / t_sim) : -(e / t_sim);
+        if (nu > nu_start && nu < nu_end) { if (emitted) lum_e += l; else lum_r += l; }
+        if (nu >= e0 && nu <= eN) {
+            // numpy: bin k holds edges[k] <= x < edges[k+1], the last bin is closed on the right; start from the uniform
+            // estimate and pin it with the actual edge values
+            int k = (int)((nu - e0) * inv_delta);
+            k = k < 0 ? 0 : (k > B - 1 ? B - 1 : k);
+            while (k > 0 && nu < edges[k]) --k;
+            while (k < B - 1 && nu >= edges[k + 1]) ++k;
+            mc::atomic_add_f64(emitted ? &hist_emitted[k] : &hist_reabsorbed[k], l);
+        }
+    }
+    // block reduction of the two luminosity sums
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = lum_e; sh[1][threadIdx.x] = lum_r;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sh[0][threadIdx.x] += sh[0][threadIdx.x + s]; sh[1][threadIdx.x] += sh[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { mc::atomic_add_f64(&lum[0], sh[0][0]); mc::atomic_add_f64(&lum[1], sh[1][0]); }
+}
+
+// ---- radiation-field update from the resident estimators (MCRadiationFieldPropertiesSolver.solve,
+// tardis/transport/montecarlo/estimators/mc_rad_field_solver.py:37-144; intensity_black_body, tardis/util/base.py:279-302)
+struct RadFieldConsts { double t_rad_const, four_sigma, jblue_norm_num, four_pi_tsim, tsim, planck_coef, h, k_b, w_epsilon, c_ang; };
+
+__global__ void radfield_shell_kernel(const double *J, const double *nubar, const double *volume, int S, RadFieldConsts k,
+                                      double *t_rad, double *w, double *norm)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const double t = k.t_rad_const * nubar[s] / J[s];
+    t_rad[s] = t;
+    const double t2 = t * t;
+    w[s] = J[s] / (k.four_sigma * (t2 * t2) * k.tsim * volume[s]);
+    norm[s] = k.jblue_norm_num / (k.four_pi_tsim * volume[s]);
+}
+
+__global__ void radfield_jblue_kernel(const double *__restrict__ jblue_t, const double *__restrict__ nu_line,
+                                      const double *__restrict__ t_rad, const double *__restrict__ w,
+                                      const double *__restrict__ norm, int S, long long L, RadFieldConsts k, int optical_window,
+                                      double *__restrict__ out_t)
+{
+    const int s = blockIdx.y;
+    const double beta = 1 / (k.k_b * t_rad[s]), ws = w[s], ns = norm[s];
+    for (long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x; l < L; l += (long long)gridDim.x * blockDim.x) {
+        const double nu = nu_line[l];
+        const double est = jblue_t[(long long)s * L + l] * ns;
+        double value = est;
+        bool outside = false;
+        if (optical_window) {
+            const double wav = k.c_ang / nu;  // Angstrom
+            outside = !(wav > 2500.0 && wav < 10000.0);
+        }
+        if (est == 0.0 || outside) {
+            const double planck = ws * (k.planck_coef * (nu * nu * nu) / (mcm::exp(k.h * nu * beta) - 1));
+            value = outside ? planck : value;
+            if (est == 0.0) value = k.w_epsilon * planck;
+        }
+        out_t[(long long)s * L + l] = value;
+    }
 }
 
 hipError_t launch_transpose(hipStream_t s, const double *in, double *out, long long rows, long long cols)
@@ -613,6 +694,184 @@ int tardis_mc_set_packets(TardisMcContext *ctx, const TardisMcPackets *p)
     return TARDIS_MC_OK;
 }
 
+/* ---- black-body packet source on the device ------------------------------------------------------- */
+namespace {
+typedef unsigned __int128 hu128;
+inline hu128 h128(uint64_t hi, uint64_t lo) { return ((hu128)hi << 64) | lo; }
+const hu128 PCG_MULT = h128(2549297995355413924ULL, 4865540595714422341ULL);  // PCG_DEFAULT_MULTIPLIER_128
+
+mc::PcgAffine affine(hu128 mult, hu128 plus)
+{
+    return mc::PcgAffine{(uint64_t)mult, (uint64_t)(mult >> 64), (uint64_t)plus, (uint64_t)(plus >> 64)};
+}
+}  // namespace
+
+int tardis_mc_pcg64_seed(uint64_t seed, uint64_t out_state[4])
+{
+    if (!out_state) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    // numpy.random.SeedSequence(seed) with an empty spawn key, pool of 4 words (numpy/random/bit_generator.pyx)
+    const uint32_t INIT_A = 0x43b0d7e5u, MULT_A = 0x931e8875u, INIT_B = 0x8b51f9ddu, MULT_B = 0x58f38dedu,
+                   MIX_L = 0xca01f9ddu, MIX_R = 0x4973f715u;
+    uint32_t entropy[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const int n_entropy = entropy[1] ? 2 : 1;
+    uint32_t hash_const = INIT_A;
+    auto hashmix = [&](uint32_t v) {
+        v ^= hash_const; hash_const *= MULT_A; v *= hash_const; v ^= v >> 16; return v;
+    };
+    auto mix = [&](uint32_t x, uint32_t y) { uint32_t r = MIX_L * x - MIX_R * y; r ^= r >> 16; return r; };
+    uint32_t pool[4];
+    for (int i = 0; i < 4; ++i) pool[i] = hashmix(i < n_entropy ? entropy[i] : 0u);
+    for (int i_src = 0; i_src < 4; ++i_src)
+        for (int i_dst = 0; i_dst < 4; ++i_dst)
+            if (i_src != i_dst) pool[i_dst] = mix(pool[i_dst], hashmix(pool[i_src]));
+    // generate_state(4, uint64): 8 words, little-endian pairs
+    uint32_t words[8];
+    uint32_t hc = INIT_B;
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = pool[i & 3];
+        v ^= hc; hc *= MULT_B; v *= hc; v ^= v >> 16;
+        words[i] = v;
+    }
+    uint64_t st[4];
+    for (int i = 0; i < 4; ++i) st[i] = (uint64_t)words[2 * i] | ((uint64_t)words[2 * i + 1] << 32);
+    // pcg64_set_seed: initstate = (st[0] high, st[1] low), initseq = (st[2] high, st[3] low); pcg_setseq_128_srandom_r
+    const hu128 initstate = h128(st[0], st[1]), initseq = h128(st[2], st[3]);
+    const hu128 inc = (initseq << 1) | 1;
+    hu128 state = 0;
+    state = state * PCG_MULT + inc;
+    state += initstate;
+    state = state * PCG_MULT + inc;
+    out_state[0] = (uint64_t)(state >> 64); out_state[1] = (uint64_t)state;
+    out_state[2] = (uint64_t)(inc >> 64); out_state[3] = (uint64_t)inc;
+    return TARDIS_MC_OK;
+}
+
+static int ensure_packet_buffers(TardisMcContext *ctx, size_t P)
+{
+    HIP_TRY(ctx, ctx->r0.ensure(P * sizeof(double)));
+    HIP_TRY(ctx, ctx->mu0.ensure(P * sizeof(double)));
+    HIP_TRY(ctx, ctx->nu0.ensure(P * sizeof(double)));
+    HIP_TRY(ctx, ctx->e0.ensure(P * sizeof(double)));
+    HIP_TRY(ctx, ctx->seeds.ensure(P * sizeof(uint32_t)));
+    HIP_TRY(ctx, ctx->out_nu.ensure(P * sizeof(double)));
+    HIP_TRY(ctx, ctx->out_e.ensure(P * sizeof(double)));
+    if (ctx->track) {
+        for (auto &b : ctx->li_f64) HIP_TRY(ctx, b.ensure(P * sizeof(double)));
+        for (auto &b : ctx->li_i64) HIP_TRY(ctx, b.ensure(P * sizeof(long long)));
+    }
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_create_blackbody_packets(TardisMcContext *ctx, int64_t n_total, int64_t first, int64_t count, double radius,
+                                       double temperature, const uint64_t pcg_state[4], uint32_t max_seed_val,
+                                       const double *l_array, int64_t n_l)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (n_total < 0 || first < 0 || count < 0 || first + count > n_total || !pcg_state || !l_array || n_l < 1 || n_l > (1 << 24) ||
+        max_seed_val < 2 || (uint64_t)n_total >= (1ULL << 44))
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "invalid packet source arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)count;
+    int rc = ensure_packet_buffers(ctx, P);
+    if (rc) return rc;
+    // jump tables of the LCG  s -> M s + inc
+    const hu128 inc = h128(pcg_state[2], pcg_state[3]);
+    std::vector<mc::PcgAffine> jump(mc::PCG_JUMP_BITS);
+    hu128 jm[mc::PCG_JUMP_BITS], jp[mc::PCG_JUMP_BITS];
+    jm[0] = PCG_MULT; jp[0] = inc;
+    for (int j = 1; j < mc::PCG_JUMP_BITS; ++j) { jm[j] = jm[j - 1] * jm[j - 1]; jp[j] = (jm[j - 1] + 1) * jp[j - 1]; }
+    for (int j = 0; j < mc::PCG_JUMP_BITS; ++j) jump[j] = affine(jm[j], jp[j]);
+    hu128 nm = 1, np_ = 0;  // n_total-step map, composed from the set bits
+    for (int j = 0; j < mc::PCG_JUMP_BITS; ++j)
+        if (((uint64_t)n_total >> j) & 1) { nm = jm[j] * nm; np_ = jm[j] * np_ + jp[j]; }
+    DevBuf d_jump, d_l, d_rej, d_cnt;
+    HIP_TRY(ctx, d_jump.ensure(jump.size() * sizeof(mc::PcgAffine)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_jump.p, jump.data(), jump.size() * sizeof(mc::PcgAffine), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, d_l.ensure((size_t)n_l * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_l.p, l_array, (size_t)n_l * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const int capacity = 1 << 16;
+    HIP_TRY(ctx, d_rej.ensure((size_t)capacity * sizeof(long long)));
+    HIP_TRY(ctx, d_cnt.ensure(sizeof(unsigned int)));
+    HIP_TRY(ctx, hipMemsetAsync(d_cnt.p, 0, sizeof(unsigned int), ctx->stream));
+
+    mc::PacketSourceArgs a{};
+    a.n_total = n_total; a.first = first; a.count = count;
+    a.state_hi = pcg_state[0]; a.state_lo = pcg_state[1];
+    a.jump = d_jump.as<mc::PcgAffine>();
+    a.step_n = affine(nm, np_);
+    a.seed_range_excl = max_seed_val;
+    a.seed_threshold = (uint32_t)((0x100000000ULL - max_seed_val) % max_seed_val);  // (UINT32_MAX - rng) % rng_excl
+    a.l_array = d_l.as<double>(); a.n_l = (int)n_l;
+    a.l_coef = 1.082323233711138;  // np.pi**4 / 90.0 (black_body.py:175)
+    a.radius = radius;
+    a.kT = 1.3806488e-16 * temperature;   // tardis/constants.py:1 (CODATA 2010, cgs)
+    a.h = 6.62606957e-27;
+    a.energy = n_total > 0 ? 1.0 / (double)n_total : 0.0;
+    a.r0 = ctx->r0.as<double>(); a.mu0 = ctx->mu0.as<double>(); a.nu0 = ctx->nu0.as<double>(); a.e0 = ctx->e0.as<double>();
+    a.seeds = ctx->seeds.as<uint32_t>();
+
+    // pass 1: rejected u32 positions of the bounded-integer draw (threshold / 2^32 of all draws; none for almost every
+    // run with the reference's MAX_SEED_VAL = 2^32 - 1)
+    std::vector<long long> rejected;
+    long long consumed_u32 = 0;
+    if (n_total > 0) {
+        unsigned int n_rej = 0;
+        if (a.seed_threshold > 0) {
+            const long long n_positions = n_total + capacity;
+            const int blocks = (int)std::min<long long>((n_positions / 2 + 255) / 256 + 1, 8192);
+            hipLaunchKernelGGL(mc::packet_source_scan_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a, n_positions,
+                               d_rej.as<long long>(), capacity, d_cnt.as<unsigned int>());
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(&n_rej, d_cnt.p, sizeof(n_rej), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if ((long long)n_rej >= capacity)
+                return fail(ctx, TARDIS_MC_ERR_UNSUPPORTED, "packet source: too many rejected seed draws for this seed range");
+            rejected.resize(n_rej);
+            if (n_rej) {
+                HIP_TRY(ctx, hipMemcpy(rejected.data(), d_rej.p, n_rej * sizeof(long long), hipMemcpyDeviceToHost));
+                std::sort(rejected.begin(), rejected.end());
+                HIP_TRY(ctx, hipMemcpy(d_rej.p, rejected.data(), n_rej * sizeof(long long), hipMemcpyHostToDevice));
+            }
+        }
+        long long pos = n_total - 1;
+        for (size_t k = 0; k < rejected.size() && rejected[k] <= pos; ++k) ++pos;
+        consumed_u32 = pos + 1;
+    }
+    a.rejected = d_rej.as<long long>();
+    a.n_rejected = (int)rejected.size();
+    a.xi_first_u64 = (consumed_u32 + 1) / 2;
+    if (count > 0) {
+        const int blocks = (int)std::min<long long>((count + 255) / 256, 16384);
+        hipLaunchKernelGGL(mc::packet_source_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    d_jump.release(); d_l.release(); d_rej.release(); d_cnt.release();
+    ctx->n_packets = count;
+    ctx->have_packets = true;
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_get_packets(TardisMcContext *ctx, double *initial_radii, double *initial_nus, double *initial_mus,
+                          double *initial_energies, int64_t *packet_seeds)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_packets) return fail(ctx, TARDIS_MC_ERR_STATE, "no packets resident");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ctx->n_packets;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (initial_radii && P) HIP_TRY(ctx, hipMemcpy(initial_radii, ctx->r0.p, P * 8, hipMemcpyDeviceToHost));
+    if (initial_nus && P) HIP_TRY(ctx, hipMemcpy(initial_nus, ctx->nu0.p, P * 8, hipMemcpyDeviceToHost));
+    if (initial_mus && P) HIP_TRY(ctx, hipMemcpy(initial_mus, ctx->mu0.p, P * 8, hipMemcpyDeviceToHost));
+    if (initial_energies && P) HIP_TRY(ctx, hipMemcpy(initial_energies, ctx->e0.p, P * 8, hipMemcpyDeviceToHost));
+    if (packet_seeds && P) {
+        std::vector<uint32_t> tmp(P);
+        HIP_TRY(ctx, hipMemcpy(tmp.data(), ctx->seeds.p, P * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < P; ++i) packet_seeds[i] = (int64_t)tmp[i];
+    }
+    return TARDIS_MC_OK;
+}
+
 int tardis_mc_reset_estimators(TardisMcContext *ctx)
 {
     if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
@@ -663,7 +922,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // init_err lives on this stack frame
     // the cooperative kernel relies on a sorted line list (bucket index, monotone stopping predicate); anything else --
     // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
-    const bool cooperative = ctx->variant == 1 && ctx->lines_sorted && (!vpk || c.number_of_vpackets <= 32);
+    const bool cooperative = (ctx->variant == 1 || ctx->variant == 2) && ctx->lines_sorted && (!vpk || c.number_of_vpackets <= 32);
 
     if (!cooperative) {
         // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment
@@ -715,11 +974,20 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         using KernelFn = void (*)(mc::GroupArgs, uint32_t *, long long, long long);
         KernelFn k;
         const bool full = c.enable_full_relativity != 0, trk = ctx->track;
+        // variant 2: wave-owner kernel (lane-per-packet event code, groups as sweep workers); no v-packets yet
+        const bool wave_kernel = ctx->variant == 2 && !vpk;
+        const size_t wave_lds = trk ? mc::wave_kernel_lds_bytes<true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false>(ctx->n_shells);
+        if (wave_kernel && wave_lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
+        const int wave_waves_per_cu = std::max(1, std::min(ctx->waves_per_simd > 0 ? 4 * ctx->waves_per_simd : 16, (int)((160 * 1024) / wave_lds)));
 #define TMC_PICK2(G_, V_) (full ? (trk ? mc::propagate_group_kernel<true, true, G_, 256, 4, V_> : mc::propagate_group_kernel<true, false, G_, 256, 4, V_>) \
                                 : (trk ? mc::propagate_group_kernel<false, true, G_, 256, 4, V_> : mc::propagate_group_kernel<false, false, G_, 256, 4, V_>))
         if (G == 16) k = vpk ? TMC_PICK2(16, true) : TMC_PICK2(16, false);
         else k = vpk ? TMC_PICK2(8, true) : TMC_PICK2(8, false);
 #undef TMC_PICK2
+#define TMC_PICKW(G_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_> : mc::propagate_wave_kernel<true, false, G_>) \
+                            : (trk ? mc::propagate_wave_kernel<false, true, G_> : mc::propagate_wave_kernel<false, false, G_>))
+        if (wave_kernel) k = (G == 16) ? TMC_PICKW(16) : TMC_PICKW(8);
+#undef TMC_PICKW
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
         ctx->chunks_timed = 0;
         for (long long first = 0; first < ctx->n_packets; first += chunk) {
@@ -739,6 +1007,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const int groups_per_block = block / G;
             long long want_blocks = (count + groups_per_block - 1) / groups_per_block;
             int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)cus * blocks_per_cu));
+            if (wave_kernel) {
+                const long long want_waves = (count + 63) / 64;
+                const int waves = (int)std::max<long long>(1, std::min<long long>(want_waves, (long long)cus * wave_waves_per_cu));
+                hipLaunchKernelGGL(k, dim3(waves), dim3(64), wave_lds, ctx->stream, P, ctx->seeded_states.as<uint32_t>(), first, count);
+            } else
             hipLaunchKernelGGL(k, dim3(blocks), dim3(block), lds, ctx->stream, P, ctx->seeded_states.as<uint32_t>(), first, count);
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3 * ci + 2], ctx->stream));
@@ -909,6 +1182,87 @@ int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const Ta
     if ((rc = tardis_mc_propagate(ctx))) return rc;
     if ((rc = tardis_mc_synchronize(ctx))) return rc;
     return tardis_mc_get_results(ctx, result);
+}
+
+int tardis_mc_packet_spectrum(TardisMcContext *ctx, double time_of_simulation, double luminosity_nu_start,
+                              double luminosity_nu_end, double *emitted_luminosity_hist, double *reabsorbed_luminosity_hist,
+                              double *out_emitted_luminosity, double *out_reabsorbed_luminosity)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_packets || !ctx->have_config || ctx->cfg.n_spectrum_grid < 2)
+        return fail(ctx, TARDIS_MC_ERR_STATE, "packet spectrum needs propagated packets and a spectrum grid");
+    if (!(time_of_simulation > 0)) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "time_of_simulation must be positive");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t B = (size_t)ctx->cfg.n_spectrum_grid - 1;
+    DevBuf work;
+    HIP_TRY(ctx, work.ensure((2 * B + 2) * sizeof(double)));
+    HIP_TRY(ctx, hipMemsetAsync(work.p, 0, (2 * B + 2) * sizeof(double), ctx->stream));
+    double *w = work.as<double>();
+    if (ctx->n_packets > 0) {
+        const int blocks = (int)std::min<long long>((ctx->n_packets + 255) / 256, 4096);
+        hipLaunchKernelGGL(spectrum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ctx->out_nu.as<double>(), ctx->out_e.as<double>(),
+                           ctx->n_packets, ctx->grid.as<double>(), (int)ctx->cfg.n_spectrum_grid, time_of_simulation,
+                           luminosity_nu_start, luminosity_nu_end, w, w + B, w + 2 * B);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    double lum[2] = {0, 0};
+    if (emitted_luminosity_hist) HIP_TRY(ctx, hipMemcpyAsync(emitted_luminosity_hist, w, B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (reabsorbed_luminosity_hist) HIP_TRY(ctx, hipMemcpyAsync(reabsorbed_luminosity_hist, w + B, B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(lum, w + 2 * B, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (out_emitted_luminosity) *out_emitted_luminosity = lum[0];
+    if (out_reabsorbed_luminosity) *out_reabsorbed_luminosity = lum[1];
+    work.release();
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_radiation_field(TardisMcContext *ctx, double time_of_simulation, const double *volume, double w_epsilon,
+                              int detailed_optical_window, double *t_radiative, double *dilution_factor, double *j_blues)
+{
+    if (!ctx || !volume) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->est_valid || !ctx->have_opacity || !ctx->have_geometry)
+        return fail(ctx, TARDIS_MC_ERR_STATE, "radiation field update needs propagated estimators");
+    if (!(time_of_simulation > 0)) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "time_of_simulation must be positive");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = reduce_estimator_copies(ctx);
+    if (rc) return rc;
+    const size_t S = ctx->est_S, L = ctx->est_L;
+    EstLayout e = est_layout(S, L, ctx->est_G, ctx->est_copies);
+    double *base = ctx->est.as<double>();
+    // constants, tardis/constants.py:1 (CODATA 2010, cgs)
+    const double h = 6.62606957e-27, k_b = 1.3806488e-16, sigma_sb = 5.670373e-5, c = mc::C_LIGHT, zeta5 = 1.0369277551433699;
+    const double pi = 3.141592653589793;
+    RadFieldConsts k;
+    k.t_rad_const = (pi * pi * pi * pi / (15 * 24 * zeta5)) * (h / k_b);
+    k.four_sigma = 4 * sigma_sb;
+    k.jblue_norm_num = c * ctx->t_exp;
+    k.four_pi_tsim = 4 * pi * time_of_simulation;
+    k.tsim = time_of_simulation;
+    k.planck_coef = 2 * h / (c * c);
+    k.h = h; k.k_b = k_b; k.w_epsilon = w_epsilon; k.c_ang = c * 1e8;
+    DevBuf work, out_t;
+    HIP_TRY(ctx, work.ensure(4 * S * sizeof(double)));
+    double *d_vol = work.as<double>(), *d_t = d_vol + S, *d_w = d_t + S, *d_norm = d_w + S;
+    HIP_TRY(ctx, hipMemcpyAsync(d_vol, volume, S * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(radfield_shell_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, ctx->stream, base + e.J, base + e.nubar,
+                       d_vol, (int)S, k, d_t, d_w, d_norm);
+    HIP_TRY(ctx, hipGetLastError());
+    if (t_radiative) HIP_TRY(ctx, hipMemcpyAsync(t_radiative, d_t, S * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (dilution_factor) HIP_TRY(ctx, hipMemcpyAsync(dilution_factor, d_w, S * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (j_blues && L > 0) {
+        HIP_TRY(ctx, out_t.ensure(L * S * sizeof(double)));
+        HIP_TRY(ctx, ctx->staging.ensure(L * S * sizeof(double)));
+        const unsigned bx = (unsigned)std::min<size_t>((L + 255) / 256, 1024);
+        hipLaunchKernelGGL(radfield_jblue_kernel, dim3(bx, (unsigned)S), dim3(256), 0, ctx->stream, base + e.jblue,
+                           ctx->nu_line.as<double>(), d_t, d_w, d_norm, (int)S, (long long)L, k, detailed_optical_window,
+                           out_t.as<double>());
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, launch_transpose(ctx->stream, out_t.as<double>(), ctx->staging.as<double>(), (long long)S, (long long)L));
+        HIP_TRY(ctx, hipMemcpyAsync(j_blues, ctx->staging.p, L * S * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    work.release(); out_t.release();
+    return TARDIS_MC_OK;
 }
 
 /* ---- multi-GPU -------------------------------------------------------------------------------------- */

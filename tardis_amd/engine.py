@@ -124,6 +124,56 @@ class Engine:
         self._check(rc, "get_results", int(res.struct.first_error_packet))
         return res
 
+    def create_blackbody_packets(self, n_packets: int, radius: float, temperature: float, base_seed: int = 23111963,
+                                 seed_offset: int = 0, *, first: int = 0, count: int | None = None,
+                                 max_seed_val: int = 2**32 - 1, l_samples: int = 1000) -> None:
+        """BlackBodySimpleSource.create_packets on the device (packet_source/base.py:195-253): the packets
+        np.random.default_rng(base_seed + seed_offset) would have produced, slice [first, first+count), left resident
+        as this engine's packet inputs."""
+        count = n_packets - first if count is None else count
+        st = (C.c_uint64 * 4)()
+        self._check(self._L.tardis_mc_pcg64_seed(int(base_seed + seed_offset), st), "pcg64_seed")
+        l_array = np.cumsum(np.arange(1, l_samples, dtype=np.float64) ** -4)  # black_body.py:174
+        self._check(self._L.tardis_mc_create_blackbody_packets(self._h, int(n_packets), int(first), int(count), float(radius),
+                                                               float(temperature), st, int(max_seed_val),
+                                                               l_array.ctypes.data, len(l_array)), "create_blackbody_packets")
+        self.n_packets = int(count)
+
+    def get_packets(self) -> dict:
+        n = self.n_packets
+        out = {k: np.empty(n) for k in ("initial_radii", "initial_nus", "initial_mus", "initial_energies")}
+        out["packet_seeds"] = np.empty(n, dtype=np.int64)
+        self._check(self._L.tardis_mc_get_packets(self._h, *(out[k].ctypes.data for k in
+                                                             ("initial_radii", "initial_nus", "initial_mus", "initial_energies",
+                                                              "packet_seeds"))), "get_packets")
+        return out
+
+    def packet_spectrum(self, time_of_simulation: float, luminosity_nu_start: float = 0.0,
+                        luminosity_nu_end: float = float("inf")) -> dict:
+        """Real-packet spectrum and filtered luminosities computed on the device from the resident packet outputs
+        (what SpectrumSolver.montecarlo_emitted/reabsorbed_luminosity and calculate_filtered_luminosity return)."""
+        B = self.n_grid - 1
+        he, hr = np.zeros(B), np.zeros(B)
+        le, lr = C.c_double(), C.c_double()
+        self._check(self._L.tardis_mc_packet_spectrum(self._h, float(time_of_simulation), float(luminosity_nu_start),
+                                                      float(luminosity_nu_end), he.ctypes.data, hr.ctypes.data,
+                                                      C.byref(le), C.byref(lr)), "packet_spectrum")
+        return {"montecarlo_emitted_luminosity": he, "montecarlo_reabsorbed_luminosity": hr,
+                "emitted_luminosity": le.value, "reabsorbed_luminosity": lr.value}
+
+    def radiation_field(self, time_of_simulation: float, volume, w_epsilon: float = 1e-10,
+                        detailed_optical_window: bool = False, want_j_blues: bool = True) -> dict:
+        """MCRadiationFieldPropertiesSolver.solve (estimators/mc_rad_field_solver.py:37-144) on the resident estimators."""
+        volume = np.ascontiguousarray(volume, dtype=np.float64)
+        if volume.shape != (self.n_shells,):
+            raise ValueError("volume must have one entry per shell")
+        t_rad, w = np.empty(self.n_shells), np.empty(self.n_shells)
+        jb = np.empty((self.n_lines, self.n_shells)) if want_j_blues else None
+        self._check(self._L.tardis_mc_radiation_field(self._h, float(time_of_simulation), volume.ctypes.data, float(w_epsilon),
+                                                      int(detailed_optical_window), t_rad.ctypes.data, w.ctypes.data,
+                                                      jb.ctypes.data if jb is not None else None), "radiation_field")
+        return {"t_radiative": t_rad, "dilution_factor": w, "j_blues": jb}
+
     # -- multi-GPU
     @staticmethod
     def comm_unique_id() -> bytes:

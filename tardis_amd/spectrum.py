@@ -23,3 +23,17 @@ def relative_l2(a, b) -> float:
     den = float(np.sqrt(np.sum(b * b)))
     num = float(np.sqrt(np.sum((a - b) ** 2)))
     return num / den if den > 0 else (0.0 if num == 0 else float("inf"))
+
+
+def reabsorbed_luminosity_histogram(output_nus, output_energies, time_of_simulation, spectrum_frequency_grid):
+    """SpectrumSolver.montecarlo_reabsorbed_luminosity (tardis/spectrum/base.py:140-148)."""
+    mask = output_energies < 0
+    lum = -(output_energies[mask] / time_of_simulation)
+    hist, _ = np.histogram(output_nus[mask], weights=lum, bins=spectrum_frequency_grid)
+    return hist
+
+
+def calculate_filtered_luminosity(packet_nu, packet_luminosity, luminosity_nu_start=0.0, luminosity_nu_end=np.inf):
+    """tardis/spectrum/luminosity.py:5-30 on plain arrays."""
+    f = (packet_nu > luminosity_nu_start) & (packet_nu < luminosity_nu_end)
+    return packet_luminosity[f].sum()

@@ -283,3 +283,41 @@ def test_baseline_config2_full_size(engine, oracle):
     a = spectrum.emitted_luminosity_histogram(nus[:n], ens[:n], pc.time_of_simulation, prob.spectrum_frequency_grid)
     b = spectrum.emitted_luminosity_histogram(ref.output_nus, ref.output_energies, pc.time_of_simulation, prob.spectrum_frequency_grid)
     assert spectrum.relative_l2(a, b) == 0.0
+
+
+def test_device_packet_spectrum_matches_numpy(engine):
+    """real-packet spectrum and filtered luminosities reduced on the device.  Bin ASSIGNMENT follows
+    numpy.histogram exactly (checked through exact per-bin sums); the weighted sums agree with numpy's own
+    (cumsum-difference) result to its accuracy."""
+    import math
+    from tardis_amd import spectrum
+    prob = synthetic.make_problem(seed=41, n_packets=300_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch",
+                                  n_bins=2000)
+    run_hip(engine, prob, track=False)
+    pc = prob.packet_collection
+    grid = prob.spectrum_frequency_grid
+    t = pc.time_of_simulation
+    lo, hi = grid[200], grid[1500]
+    got = engine.packet_spectrum(t, lo, hi)
+    # exact reference: numpy's bin assignment (searchsorted rules) + correctly rounded per-bin sums
+    for sign, key, lkey in ((1, "montecarlo_emitted_luminosity", "emitted_luminosity"),
+                            (-1, "montecarlo_reabsorbed_luminosity", "reabsorbed_luminosity")):
+        mask = (pc.output_energies >= 0) if sign > 0 else (pc.output_energies < 0)
+        nu, lum = pc.output_nus[mask], sign * (pc.output_energies[mask] / t)
+        inside = (nu >= grid[0]) & (nu <= grid[-1])
+        idx = np.searchsorted(grid, nu[inside], "right") - 1
+        idx[nu[inside] == grid[-1]] = len(grid) - 2
+        exact = np.zeros(len(grid) - 1)
+        order = np.argsort(idx, kind="stable")
+        bounds = np.searchsorted(idx[order], np.arange(len(grid)))
+        w = lum[inside][order]
+        for b in range(len(grid) - 1):
+            exact[b] = math.fsum(w[bounds[b]:bounds[b + 1]])
+        assert_allclose(got[key], exact, rtol=1e-12, atol=0)
+        assert np.array_equal(got[key] == 0, exact == 0)                       # identical bin occupancy
+        np_hist = (spectrum.emitted_luminosity_histogram if sign > 0 else spectrum.reabsorbed_luminosity_histogram)(
+            pc.output_nus, pc.output_energies, t, grid)
+        assert_allclose(got[key], np_hist, rtol=1e-9, atol=0)
+        f = (nu > lo) & (nu < hi)
+        assert_allclose(got[lkey], math.fsum(lum[f]), rtol=1e-12)
+        assert_allclose(got[lkey], spectrum.calculate_filtered_luminosity(nu, lum, lo, hi), rtol=1e-10)

@@ -43,7 +43,7 @@ def traffic_json(root, out_path):
              "join rocpd_info_pmc p on e.pmc_id=p.id join rocpd_kernel_dispatch d on e.event_id=d.event_id "
              "join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by s.kernel_name, p.name")
         for name, counter, n, total in c.execute(q):
-            if "propagate_group" in name and counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            if ("propagate_group" in name or "propagate_wave" in name) and counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[counter] = total / n
     if len(vals) == 2:
         hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
