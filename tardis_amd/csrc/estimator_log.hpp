@@ -1,0 +1,273 @@
+// estimator_log.hpp -- deferred accumulation of the line estimators (j_blue, Edotlu).
+//
+// Why: update_line_estimators (estimators/estimators_line.py) adds to j_blue[line, shell] and Edotlu[line, shell] for
+// EVERY line a packet passes, ~375 read-modify-writes of each array per packet in the tardis_example shape.  On MI355X
+// device-scope fp64 atomics are executed memory-side (8 XCDs, 8 L2s): the PMC counters show every one of the 1.9e9
+// atomic requests of a 1e7-packet launch leaving the L2 (TCC_EA0_ATOMIC == TCC_ATOMIC), and the chip sustains ~2e10 of
+// them per second -- that request rate, not arithmetic, bounded the propagation kernel (97 ms; 62 ms with the atomics
+// stubbed out).  A trace passes a CONTIGUOUS run of lines of one shell, and the value it adds to each of them is a pure
+// function of (line, packet state at the start of the trace).  So the propagation kernel only logs one 48-byte record
+// per trace, and three small kernels turn the log into the estimators:
+//
+//   bin_count_kernel   -- histogram of the records over (shell, TILE-line tile) bins          (LDS histogram)
+//   bin_scatter_kernel -- counting sort of the record indices by bin                            (LDS ranks)
+//   accumulate_kernel  -- per bin slice: the tile's j_blue/Edotlu live in LDS, every record of the slice recomputes its
+//                         terms with the reference's arithmetic (same operation order as the sweep, so every term is
+//                         bit-identical to the one the atomics path adds) and adds them with LDS atomics; the tile is
+//                         then added to the global arrays once.
+// The sum order differs from the serial reference exactly as it does with atomics (floating-point sum of the same
+// terms in a different order).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mc_device.hpp"
+
+namespace mc {
+
+constexpr int EST_TILE = 2048;       // lines per LDS tile (2 x 16 KiB)
+constexpr int EST_SLICE = 4096;      // records per accumulate workgroup
+constexpr int EST_MAX_BINS = 16384;  // largest LDS histogram of the binning kernels (dynamic LDS, 4 B per bin = 64 KiB)
+
+struct __attribute__((aligned(16))) LineVisitRecord {
+    double energy, nu, comov_nu, mur;  // packet state at the start of the trace (mur = mu * r)
+    unsigned idx0;                     // shell * n_lines + first line visited
+    unsigned n_flags;                  // number of lines visited | (exact-division fast path << 31)
+    unsigned pad[2];
+};
+static_assert(sizeof(LineVisitRecord) == 48, "record layout");
+
+struct EstimatorLog {
+    LineVisitRecord *records;
+    unsigned *keys;                    // bin of each record
+    unsigned long long *cursor;        // next free record
+    unsigned long long capacity;
+    int tiles_per_shell;
+    int empty_bin;                     // key of a reserved but unused slot (= number of real bins)
+};
+
+// the term update_line_estimators adds for line `nu_line` (estimators_line.py; the sweep's pend_e / pend_jb)
+template <bool FULL>
+__device__ __forceinline__ void line_estimator_terms(const LineVisitRecord &rec, bool fast, double rcp_nu, double nu_line, double t_exp,
+                                                     double tc, double rcp_tc, double &e_term, double &jb_term)
+{
+    if (FULL) e_term = rec.energy;
+    else {
+        const double nu_diff = rec.comov_nu - nu_line;
+        const double q = fast ? exact_div<true>(nu_diff, rec.nu, rcp_nu) : nu_diff / rec.nu;
+        const bool close = fabs(q) < CLOSE_LINE_THRESHOLD;
+        const double d_trace = close ? 0.0 : q * C_LIGHT * t_exp;
+        const double x = d_trace + rec.mur;
+        e_term = rec.energy * (1.0 - (fast ? exact_div<true>(x, tc, rcp_tc) : x / tc));
+    }
+    jb_term = fast ? exact_div<true>(e_term, rec.nu, rcp_nu) : e_term / rec.nu;
+}
+
+__global__ void __launch_bounds__(256) bin_count_kernel(const unsigned *__restrict__ keys, const unsigned long long *__restrict__ cursor,
+                                                        unsigned long long capacity, int n_bins, unsigned *__restrict__ bin_count)
+{
+    extern __shared__ unsigned hist[];
+    const unsigned long long n = min(*cursor, capacity);
+    for (int b = threadIdx.x; b < n_bins; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256)
+        atomicAdd(&hist[keys[i]], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_bins; b += 256)
+        if (hist[b]) atomicAdd(&bin_count[b], hist[b]);
+}
+
+// one workgroup: exclusive scan of the bin counts -> bin_start[n_bins + 1]; slices of at most EST_SLICE records ->
+// slice_start[n_bins + 1] (prefix of the per-bin slice counts); bin_fill is reset to the bin starts for the scatter.
+// (bin n_bins - 1 is the "empty slot" bin: it is sorted like the others but gets no slices)
+__global__ void __launch_bounds__(256) bin_scan_kernel(const unsigned *__restrict__ bin_count, int n_bins, unsigned *__restrict__ bin_start,
+                                                       unsigned *__restrict__ bin_fill, unsigned *__restrict__ slice_start)
+{
+    auto slices = [&](int b) { return b == n_bins - 1 ? 0u : (bin_count[b] + EST_SLICE - 1) / EST_SLICE; };
+    __shared__ unsigned part_r[256], part_s[256];
+    const int per = (n_bins + 255) / 256;
+    const int b0 = threadIdx.x * per, b1 = min(n_bins, b0 + per);
+    unsigned r = 0, s = 0;
+    for (int b = b0; b < b1; ++b) { r += bin_count[b]; s += slices(b); }
+    part_r[threadIdx.x] = r; part_s[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned ar = 0, as = 0;
+        for (int k = 0; k < 256; ++k) { const unsigned tr = part_r[k], ts = part_s[k]; part_r[k] = ar; part_s[k] = as; ar += tr; as += ts; }
+    }
+    __syncthreads();
+    r = part_r[threadIdx.x]; s = part_s[threadIdx.x];
+    for (int b = b0; b < b1; ++b) {
+        bin_start[b] = r; bin_fill[b] = r; slice_start[b] = s;
+        r += bin_count[b]; s += slices(b);
+    }
+    if (b1 == n_bins && b0 <= n_bins) { bin_start[n_bins] = r; slice_start[n_bins] = s; }
+}
+
+// counting-sort scatter of the record indices: every workgroup takes a contiguous slice of the log, ranks its records
+// per bin in LDS, reserves the output ranges with one global atomic per non-empty bin and writes the indices.
+__global__ void __launch_bounds__(256) bin_scatter_kernel(const unsigned *__restrict__ keys, const unsigned long long *__restrict__ cursor,
+                                                          unsigned long long capacity, int n_bins, unsigned *__restrict__ bin_fill,
+                                                          unsigned *__restrict__ sorted_index)
+{
+    extern __shared__ unsigned hist[];
+    const unsigned long long n = min(*cursor, capacity);
+    const unsigned long long per_block = (n + gridDim.x - 1) / gridDim.x;
+    const unsigned long long first = (unsigned long long)blockIdx.x * per_block;
+    const unsigned long long last = min(n, first + per_block);
+    for (int b = threadIdx.x; b < n_bins; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (unsigned long long i = first + threadIdx.x; i < last; i += 256) atomicAdd(&hist[keys[i]], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_bins; b += 256) {
+        const unsigned c = hist[b];
+        hist[b] = c ? atomicAdd(&bin_fill[b], c) : 0u;  // base of this block's range in bin b
+    }
+    __syncthreads();
+    for (unsigned long long i = first + threadIdx.x; i < last; i += 256) {
+        const unsigned pos = atomicAdd(&hist[keys[i]], 1u);
+        sorted_index[pos] = (unsigned)i;
+    }
+}
+
+// Workgroups loop over slices (<= EST_SLICE records of one bin): the bin's tile of both estimators lives in LDS.  A wave
+// stages 64 records at a time (the next 64 are already in flight) and spreads their line visits evenly over its lanes:
+// lane l of pass i handles visit 64 i + l of the batch; the record a visit belongs to is found with one popcount on a
+// bit mask of the record starts.  Records longer than EST_LONG lines are walked by the whole wave one after the other.
+constexpr int EST_LONG = 255;
+constexpr unsigned EST_EMPTY_N = 0u;
+
+template <bool FULL, bool FAST>
+__device__ __forceinline__ void accumulate_term(double energy, double nu, double rcp_nu, double comov_nu, double mur, double nu_l,
+                                                double t_exp, double tc, double rcp_tc, double &e_term, double &jb_term)
+{
+    if (FULL) e_term = energy;
+    else {
+        const double q = exact_div<FAST>(comov_nu - nu_l, nu, rcp_nu);
+        const bool close = fabs(q) < CLOSE_LINE_THRESHOLD;
+        const double d_trace = close ? 0.0 : q * C_LIGHT * t_exp;
+        e_term = energy * (1.0 - exact_div<FAST>(d_trace + mur, tc, rcp_tc));
+    }
+    jb_term = exact_div<FAST>(e_term, nu, rcp_nu);
+}
+
+template <bool FULL>
+__global__ void __launch_bounds__(256) accumulate_kernel(const LineVisitRecord *__restrict__ records, const unsigned *__restrict__ sorted_index,
+                                                         const unsigned *__restrict__ bin_start, const unsigned *__restrict__ slice_start,
+                                                         int n_bins, int tiles_per_shell, int n_lines, const double *__restrict__ nu_line,
+                                                         double t_exp, double tc, double rcp_tc, double *__restrict__ jblue_t,
+                                                         double *__restrict__ edot_t)
+{
+    __shared__ double tile_jb[EST_TILE], tile_ed[EST_TILE];
+    __shared__ double st_energy[4][64], st_nu[4][64], st_rcp[4][64], st_cnu[4][64], st_mur[4][64];
+    __shared__ unsigned st_idx0[4][64], st_first[4][64];  // idx0 | fast << 31 is kept apart: st_fast
+    __shared__ unsigned char st_fast[4][64];
+    __shared__ unsigned long long starts[4][EST_LONG + 1];
+    const unsigned n_slices = slice_start[n_bins];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long le_mask = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    for (unsigned slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+        // bin of this slice: last b with slice_start[b] <= slice
+        int lo = 0, hi = n_bins;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (slice_start[mid] <= slice) lo = mid; else hi = mid;
+        }
+        const int bin = lo;
+        const unsigned rec_first = bin_start[bin] + (slice - slice_start[bin]) * EST_SLICE;
+        const unsigned rec_last = min(bin_start[bin + 1], rec_first + EST_SLICE);
+        const int shell = bin / tiles_per_shell, tile = bin - shell * tiles_per_shell;
+        const unsigned row = (unsigned)shell * (unsigned)n_lines;
+        const unsigned tile_idx0 = row + (unsigned)tile * EST_TILE;
+        for (int k = threadIdx.x; k < EST_TILE; k += 256) { tile_jb[k] = 0.0; tile_ed[k] = 0.0; }
+        __syncthreads();
+
+        auto add_term = [&](unsigned idx, double jb_term, double e_term) {
+            const unsigned off = idx - tile_idx0;
+            if (off < (unsigned)EST_TILE) {
+                atomicAdd(&tile_jb[off], jb_term);
+                atomicAdd(&tile_ed[off], e_term);
+            } else {  // the trace ran past the end of its first tile
+                atomic_add_f64(&jblue_t[idx], jb_term);
+                atomic_add_f64(&edot_t[idx], e_term);
+            }
+        };
+        LineVisitRecord next;
+        next.n_flags = 0;
+        {
+            const unsigned r = rec_first + (unsigned)w * 64 + (unsigned)lane;
+            if (r < rec_last) next = records[sorted_index[r]];
+        }
+        for (unsigned base = rec_first + (unsigned)w * 64; base < rec_last; base += 256) {
+            const LineVisitRecord rec = next;
+            next.n_flags = 0;
+            {
+                const unsigned r = base + 256 + (unsigned)lane;
+                if (r < rec_last) next = records[sorted_index[r]];
+            }
+            const unsigned n_all = rec.n_flags & 0x7fffffffu;
+            const bool fast = (rec.n_flags >> 31) != 0;
+            const unsigned n = n_all > (unsigned)EST_LONG ? 0u : n_all;  // long records are handled below
+            // exclusive scan of n over the wave
+            unsigned incl = n;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)incl, off);
+                if (lane >= off) incl += up;
+            }
+            const unsigned excl = incl - n;
+            const unsigned total = (unsigned)__shfl((int)incl, 63);
+            const unsigned n_pass = (total + 63) >> 6;
+            for (unsigned k = lane; k < n_pass; k += 64) starts[w][k] = 0ull;
+            const double rcp_nu = 1.0 / rec.nu;
+            if (n) {  // staged in compacted order: the q-th record that starts is the q-th staged one
+                const int pos = __popcll(__ballot(true) & ((1ull << lane) - 1ull));
+                st_energy[w][pos] = rec.energy; st_nu[w][pos] = rec.nu; st_rcp[w][pos] = rcp_nu; st_cnu[w][pos] = rec.comov_nu;
+                st_mur[w][pos] = rec.mur; st_idx0[w][pos] = rec.idx0; st_first[w][pos] = excl; st_fast[w][pos] = fast ? 1 : 0;
+                atomicOr(&starts[w][excl >> 6], 1ull << (excl & 63));
+            }
+            unsigned rec_base = 0;  // records started before this pass (wave-uniform)
+            for (unsigned i = 0; i < n_pass; ++i) {
+                const unsigned long long m = starts[w][i];
+                const unsigned t = (i << 6) + (unsigned)lane;
+                if (t < total) {
+                    const unsigned q = rec_base + (unsigned)__popcll(m & le_mask) - 1u;
+                    const unsigned idx = st_idx0[w][q] + (t - st_first[w][q]);
+                    const double nu_l = nu_line[idx - row];
+                    double e_term, jb_term;
+                    if (st_fast[w][q]) accumulate_term<FULL, true>(st_energy[w][q], st_nu[w][q], st_rcp[w][q], st_cnu[w][q], st_mur[w][q], nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
+                    else accumulate_term<FULL, false>(st_energy[w][q], st_nu[w][q], st_rcp[w][q], st_cnu[w][q], st_mur[w][q], nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
+                    add_term(idx, jb_term, e_term);
+                }
+                rec_base += (unsigned)__popcll(m);
+            }
+            // long records: the whole wave walks one record at a time
+            unsigned long long longs = __ballot(n_all > (unsigned)EST_LONG);
+            while (longs) {
+                const int q = __builtin_ctzll(longs);
+                longs &= longs - 1;
+                const unsigned len = (unsigned)__shfl((int)n_all, q);
+                const unsigned idx0 = (unsigned)__shfl((int)rec.idx0, q);
+                const bool l_fast = __shfl((int)fast, q) != 0;
+                const double l_energy = __shfl(rec.energy, q), l_nu = __shfl(rec.nu, q), l_rcp = __shfl(rcp_nu, q);
+                const double l_cnu = __shfl(rec.comov_nu, q), l_mur = __shfl(rec.mur, q);
+                for (unsigned k = lane; k < len; k += 64) {
+                    const unsigned idx = idx0 + k;
+                    const double nu_l = nu_line[idx - row];
+                    double e_term, jb_term;
+                    if (l_fast) accumulate_term<FULL, true>(l_energy, l_nu, l_rcp, l_cnu, l_mur, nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
+                    else accumulate_term<FULL, false>(l_energy, l_nu, l_rcp, l_cnu, l_mur, nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
+                    add_term(idx, jb_term, e_term);
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned tile_len = min((unsigned)EST_TILE, (unsigned)n_lines - (unsigned)tile * EST_TILE);
+        for (unsigned k = threadIdx.x; k < tile_len; k += 256) {
+            if (tile_jb[k] != 0.0) atomic_add_f64(&jblue_t[tile_idx0 + k], tile_jb[k]);
+            if (tile_ed[k] != 0.0) atomic_add_f64(&edot_t[tile_idx0 + k], tile_ed[k]);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace mc

@@ -156,24 +156,31 @@ __device__ __forceinline__ double dpp_row_shr1_zero(double v)
 // ((carry + v0) + v1) + ... + vj for lane j: the reference's sequential accumulation order, evaluated exactly.
 // acc <- shr1(acc) + v repeated G-1 times: after step s lanes 0..s hold their final value and recomputing a final
 // lane from its (final) left neighbour reproduces the same value, so no per-step masking is needed.
+// lane j <- value of lane j-1 of its 16-lane DPP row, AND-ed with a per-lane bit mask; +0.0 is shifted into lane 0 of the
+// row.  Written so that the DPP move folds into the v_and (one instruction per 32-bit half).
+__device__ __forceinline__ double dpp_row_shr1_and(double v, int mask)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, true) & mask;
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, true) & mask;
+    return __hiloint2double(hi, lo);
+}
+
 template <int G>
 __device__ __forceinline__ double serial_prefix(double carry, double v, int j)
 {
     const double head = carry + v;  // value of the group's first lane
     double acc = head;
+    // lane 0 adds its head to +0.0 (exact), every other lane adds its own v to its left neighbour's running value
+    const double addend = (j == 0) ? head : v;
     if (G == 16) {
-        // lane 0 adds its head to the +0.0 shifted in (exact), every other lane adds its own v to its left neighbour
-        const double addend = (j == 0) ? head : v;
 #pragma unroll
         for (int s = 1; s < G; ++s) acc = dpp_row_shr1_zero(acc) + addend;
     } else {
+        // a smaller group shares its DPP row with neighbour groups: what arrives from the neighbour is masked to +0.0
+        int keep = (j == 0) ? 0 : -1;
+        asm volatile("" : "+v"(keep));  // keep it a plain bit mask: v_and_b32 can take the DPP operand, v_cndmask cannot
 #pragma unroll
-        for (int s = 1; s < G; ++s) {
-            // an 8-lane group shares its DPP row with a neighbour group: lane 0 is re-pinned explicitly
-            double prev = dpp_row_shr1(acc, acc);
-            acc = prev + v;
-            acc = (j == 0) ? head : acc;
-        }
+        for (int s = 1; s < G; ++s) acc = dpp_row_shr1_and(acc, keep) + addend;
     }
     return acc;
 }

@@ -14,70 +14,87 @@
 //                   were prefetched while the previous sweep was still running.  All groups stay busy until the pool
 //                   is empty, so the sweep cost follows the MEAN sweep length.
 //
-// The arithmetic of a trace is the group kernel's (same operation order, same serial optical-depth scan, same deferred
-// estimator atomics), so per-packet results stay bit-identical to the CPU oracle.  Sweep parameters travel from the
-// owner lane to the worker group through LDS (written once in the prologue) and two cross-lane reads; the stopping
-// line / distance come back through LDS.  MT19937: the packet's state stays in global memory (seeded by
+// The arithmetic of a trace is the group kernel's (same operation order, same serial optical-depth scan), so per-packet
+// results stay bit-identical to the CPU oracle.  Sweep parameters travel from the owner lane to the worker group
+// through LDS (written once in the prologue); the stopping line / distance come back through LDS.  The line estimators
+// are not updated by the sweep at all: the owner lane logs one record per trace and the kernels of estimator_log.hpp
+// turn the log into j_blue / Edotlu (the memory-side fp64 atomics were what bounded the group kernel).  MT19937: the packet's state stays in global memory (seeded by
 // seed_states_kernel) and is advanced 8 words at a time by 8-lane subgroups with coalesced accesses; the tempered
 // doubles are parked in a per-lane LDS ring from which the lane-per-packet code pops its draws.
 #pragma once
 #include "mc_device.hpp"
 #include "propagate_group.hpp"
+#include "estimator_log.hpp"
 
 namespace mc {
 
 constexpr int WV_RING = 8;  // look-ahead doubles per packet (power of two, >= 8: a refill adds 4)
-enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_POOL = 2, WS_ASSIGNED = 3, WS_READY = 4, WS_DONE = 5 };
+enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3 };
 constexpr int RES_PENDING = -1;
 
 // per-wave LDS, structure of arrays indexed by lane
 struct WaveShared {
-    double comov_nu[64], chi[64], rcp_nu[64], rcp_chi[64], tau_event[64], mur[64];
+    double nu[64], rcp_nu[64], comov_nu[64], chi[64], rcp_chi[64], tau_event[64];
     double d_boundary[64];  // in: boundary distance of the prepared trace; out: distance of the event found
     double ring[WV_RING][64];
+    int cursor[64], rowfast[64];  // first line of the trace; shell * n_lines | exact-division fast path << 31
     int res_info[64], res_line[64];
+    int queue[64];                // lanes whose prepared trace waits for a worker group
 };
-struct WaveTracker {  // packets/trackers/tracker_last_interaction.py:8-254; nu/energy/after_nu/after_energy are the
-    double radius[64], before_nu[64], before_mu[64], before_energy[64], after_mu[64];  // packet's final nu and energy
-    int shell_id[64], interaction_type[64], line_absorb_id[64], line_emit_id[64], interactions_count[64], boundary_buffer[64];
+struct WaveSharedFull {  // only read by the full-relativity sweep
+    double r[64], mu[64];
+};
+// Last-interaction tracker (packets/trackers/tracker_last_interaction.py:8-254): write-only until the packet ends, so it
+// lives in a global scratch slot of the wave (structure of arrays over the wave's lanes: every store is one coalesced
+// 256/512-byte write that stays in L2); nu/energy/after_nu/after_energy are the packet's final nu and energy.
+struct WaveTracker {
+    double radius[64], before_nu[64], before_mu[64], before_energy[64], after_mu[64];
+    int shell_id[64], line_absorb_id[64], line_emit_id[64], interaction_type[64];
 };
 
-template <bool TRACK>
+template <bool FULL>
 __host__ __device__ constexpr size_t wave_kernel_lds_bytes(int n_shells)
 {
-    return sizeof(WaveShared) + (TRACK ? sizeof(WaveTracker) : 0) + 2 * (size_t)n_shells * sizeof(double);
+    return sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0) + 2 * (size_t)n_shells * sizeof(double);
 }
+
+// Kernel arguments.  Only what the sweep loop touches is passed by value (-> SGPRs); everything the event phase needs is
+// read through `cold` (a device copy) at the top of every pass, so that it does not occupy scalar registers -- and, once
+// those run out, VGPR lanes -- during the sweeps.
+struct WaveHot {
+    const double *nu_line, *tau_t;
+    int n_lines, n_shells, disable_line_scattering, debug_flags;
+    double t_exp, tc, rcp_tc;
+};
+struct WaveTracker;
+struct WaveCold {
+    GroupArgs P;
+    EstimatorLog log;
+    uint32_t *seeded_states;
+    WaveTracker *tracker_scratch;
+    long long chunk_first, chunk_count;
+};
 
 // One worker slot of a group: the trace it is sweeping (group-uniform values) and this lane's line of the current chunk.
 struct SweepSlot {
     int owner;  // lane (in this wave) of the packet being traced, -1: idle
-    double nu, energy, mur, r, mu;
-    double comov_nu, chi, rcp_nu, rcp_chi, tau_event, d_boundary;
+    double nu, rcp_nu, comov_nu, chi, rcp_chi, tau_event, d_boundary, r, mu;
     double tau_carry, d_cont_carry;
     double nu_line, tau_line;
     int cur0;
     unsigned row;
     bool fast;
-    bool pend_valid;
-    unsigned pend_idx;
-    double pend_e, pend_jb;
 };
 
 // One G-line step of the line sweep of trace_packet (modes/homologous_rad_packet_transport.py:100-172); the loop body of
-// sweep_lines() in propagate_group.hpp with the loop turned inside out.  On a stop (or when the list is exhausted) the
-// result is handed to the owner lane through LDS and the slot becomes idle.
+// sweep_lines() in propagate_group.hpp with the loop turned inside out and without the estimator updates.  On a stop
+// (or when the list is exhausted) the result is handed to the owner lane through LDS and the slot becomes idle.
 template <bool FULL, int G, bool FAST>
-__device__ __forceinline__ void sweep_step(const GroupArgs &P, SweepSlot &s, const int j, double *__restrict__ jb,
-                                           double *__restrict__ ed, WaveShared &sh, unsigned long long &visits)
+__device__ __forceinline__ void sweep_step(const WaveHot &P, SweepSlot &s, const int j, WaveShared &sh, unsigned long long &visits)
 {
     const int L = P.n_lines;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);
     constexpr unsigned long long GMASK = (G == 16) ? 0xffffull : ((G == 8) ? 0xffull : 0xfull);
-    if (s.pend_valid && !(P.debug_flags & 1)) {
-        atomic_add_f64(&jb[s.pend_idx], s.pend_jb);
-        atomic_add_f64(&ed[s.pend_idx], s.pend_e);
-    }
-    s.pend_valid = false;
     int info = 0, res_line = 0;
     double distance = 0.0;
     bool finished = false;
@@ -90,8 +107,8 @@ __device__ __forceinline__ void sweep_step(const GroupArgs &P, SweepSlot &s, con
         const double nu_next = nin ? P.nu_line[(unsigned)nline] : 0.0;
         const double tau_next = nin ? P.tau_t[s.row + (unsigned)nline] : 0.0;
 
-        const double nu_line = s.nu_line, tau_line = s.tau_line;
-        const double tau_incl = serial_prefix<G>(s.tau_carry, tau_line, j);
+        const double nu_line = s.nu_line;
+        const double tau_incl = serial_prefix<G>(s.tau_carry, s.tau_line, j);
         const double tau_prev = group_shr1<G>(s.tau_carry, tau_incl, j);
         const double d_cont = (j == 0) ? s.d_cont_carry : exact_div<FAST>(s.tau_event - tau_prev, s.chi, s.rcp_chi);
         const bool is_last = line == L - 1;
@@ -113,25 +130,15 @@ __device__ __forceinline__ void sweep_step(const GroupArgs &P, SweepSlot &s, con
         const bool stop_l = ok && !stop_b && !stop_e && tau_combined > s.tau_event && !P.disable_line_scattering;
         const bool stop = stop_b || stop_e || stop_l || (in_range && err);
         const unsigned stop_mask = (unsigned)((__ballot(stop) >> gshift) & GMASK);
-        const int first = stop_mask ? __builtin_ctz(stop_mask) : G;
-        const int code = stop_b ? 1 : (stop_e ? 2 : (stop_l ? 3 : ((in_range && err) ? 4 : 0)));
-        const int first_code = gbcast<G>(code, first & (G - 1));
-        const bool visited = in_range && (j < first || (j == first && first_code == 3));
-        double pend_e;
-        if (!FULL) pend_e = s.energy * (1.0 - exact_div<FAST>(d_trace + s.mur, P.tc, P.rcp_tc));
-        else pend_e = s.energy;
-        s.pend_valid = visited;
-        s.pend_idx = s.row + (unsigned)line;
-        s.pend_e = pend_e;
-        s.pend_jb = exact_div<FAST>(pend_e, s.nu, s.rcp_nu);
-        if (first < G) {
+        if (stop_mask) {
+            const int first = __builtin_ctz(stop_mask);
+            const int code = stop_b ? 1 : (stop_e ? 2 : (stop_l ? 3 : 4));
             visits += (unsigned long long)(first + 1);
             finished = true;
-            info = first_code;
+            info = gbcast<G>(code, first);
             res_line = s.cur0 + first;
-            if (first_code == 1) distance = s.d_boundary;
-            else if (first_code == 2) distance = gbcast<G>(d_cont, first);
-            else distance = gbcast<G>(d_trace, first & (G - 1));
+            const double d_sel = stop_b ? s.d_boundary : (stop_e ? d_cont : d_trace);
+            distance = gbcast<G>(d_sel, first);
         } else {
             const int n_in = min(G, L - s.cur0);
             visits += (unsigned long long)n_in;
@@ -148,11 +155,6 @@ __device__ __forceinline__ void sweep_step(const GroupArgs &P, SweepSlot &s, con
         else { distance = s.d_boundary; info = 1 | 8; }
     }
     if (finished) {
-        if (s.pend_valid && !(P.debug_flags & 1)) {
-            atomic_add_f64(&jb[s.pend_idx], s.pend_jb);
-            atomic_add_f64(&ed[s.pend_idx], s.pend_e);
-        }
-        s.pend_valid = false;
         if (j == 0) {
             sh.d_boundary[s.owner] = distance;
             sh.res_line[s.owner] = res_line;
@@ -163,24 +165,20 @@ __device__ __forceinline__ void sweep_step(const GroupArgs &P, SweepSlot &s, con
 }
 
 template <bool FULL, bool TRACK, int G>
-__global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_t *__restrict__ seeded_states, long long chunk_first,
-                                                            long long chunk_count)
+__global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     WaveShared &sh = *reinterpret_cast<WaveShared *>(lds_raw);
-    WaveTracker &trk = *reinterpret_cast<WaveTracker *>(lds_raw + sizeof(WaveShared));
-    double *lds_J = reinterpret_cast<double *>(lds_raw + sizeof(WaveShared) + (TRACK ? sizeof(WaveTracker) : 0));
-    double *lds_nubar = lds_J + P.n_shells;
+    WaveSharedFull &shf = *reinterpret_cast<WaveSharedFull *>(lds_raw + sizeof(WaveShared));
+    double *lds_J = reinterpret_cast<double *>(lds_raw + sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0));
+    double *lds_nubar = lds_J + H.n_shells;
     const int lane = threadIdx.x;  // one wave per workgroup
-    for (int s = lane; s < 2 * P.n_shells; s += 64) lds_J[s] = 0.0;
+    for (int s = lane; s < 2 * H.n_shells; s += 64) lds_J[s] = 0.0;
 
     const int j = lane & (G - 1);
     const int group_lane0 = lane & ~(G - 1);
-    const int copy = P.n_est_copies > 1 ? (xcc_id() % P.n_est_copies) : 0;
-    double *jb = P.jblue_t + (size_t)copy * P.est_copy_stride;
-    double *ed = P.edot_t + (size_t)copy * P.est_copy_stride;
-    const double t = P.t_exp;
-    const int L = P.n_lines;
+    const double t = H.t_exp;
+    const int L = H.n_lines;
 
     // ---- owner-lane state: this lane's packet
     Packet p;
@@ -191,17 +189,14 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_
     int pflags = 0;       // bit 0: exact-division fast path is safe; bits 1-2: delta_shell + 1
     int r_gpos = 0, r_head = 0, r_cnt = 0;  // MT19937: next state block to regenerate; LDS ring of tempered doubles
     unsigned draws = 0, events = 0, macro = 0;
+    int trk_count = 0, trk_boundary = 0;  // interactions_count, boundary crossings since the last interaction
+    bool trk_any = false;
     bool exhausted = false;  // wave-uniform: the chunk has no more packets
-    // ---- worker state of this lane's group
-    SweepSlot cur;
-    cur.owner = -1; cur.pend_valid = false; cur.cur0 = 0; cur.row = 0; cur.fast = true;
-    cur.nu = cur.energy = cur.mur = cur.r = cur.mu = cur.comov_nu = cur.chi = cur.rcp_nu = cur.rcp_chi = 0.0;
-    cur.tau_event = cur.d_boundary = cur.tau_carry = cur.d_cont_carry = cur.nu_line = cur.tau_line = 0.0;
-    cur.pend_idx = 0; cur.pend_e = cur.pend_jb = 0.0;
-    int nxt_owner = -1, n_cursor = 0;
-    unsigned n_row = 0;
-    double n_nu = 0.0, n_tau = 0.0;
+    int q_head = 0, q_tail = 0;  // wave-uniform: queue of prepared traces
+    unsigned long long log_next = 0;  // lane 0: first of the 64 log slots reserved for the next pass
+    if (lane == 0) log_next = atomicAdd(W->log.cursor, 64ull);
     unsigned long long visits = 0;
+    unsigned dbg_rounds = 0;  // wave-uniform profiling counter: sweep rounds (reported through counters[7])
 
     auto draw = [&]() {
         const double v = sh.ring[r_head][lane];
@@ -212,7 +207,7 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_
     };
     // wave-uniform: give every lane of `need` four more doubles (8 stream words, regenerated in place by an 8-lane
     // subgroup with coalesced accesses; 624 = 78 * 8, so a block never wraps)
-    auto refill = [&](unsigned long long need) {
+    auto refill = [&](unsigned long long need, uint32_t *seeded_states) {
         const int sj = lane & 7;
         while (need) {
             int my_owner = -1;
@@ -252,64 +247,113 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_
 
     for (;;) {
         // ============================================================ event phase (lane-per-packet)
-        // ---- epilogue of the finished traces: move, estimators, boundary / scattering
-        refill(__ballot(state == WS_READY && r_cnt < 2));
-        int err = 0, type = 0, emit = -1, absorb = -1, mb0 = 0, mb1 = 0;
-        double inv_new = 1.0, before_nu = 0.0, before_mu = 0.0, before_energy = 0.0, scat_comov_nu = 0.0;
+        asm volatile("" ::: "memory");  // the cold arguments are (re)loaded here, once per pass
+        const GroupArgs &P = W->P;
+        const EstimatorLog &log = W->log;
+        uint32_t *const seeded_states = W->seeded_states;
+        WaveTracker &trk = W->tracker_scratch[TRACK ? blockIdx.x : 0];
+        const long long chunk_first = W->chunk_first, chunk_count = W->chunk_count;
+        double *const jb = P.jblue_t, *const ed = P.edot_t;
+        // every live packet gets the draws of one pass: new direction, first macro-atom jump, next tau_event
+        const bool ready = state == WS_SWEEP;  // every prepared trace has been swept
+        refill(__ballot((ready || state == WS_NEED_TRACE) && r_cnt < 3), seeded_states);
+        int err = 0, type = 0, emit = -1, mb0 = 0, mb1 = 0;
+        double inv_new = 1.0, distance = 0.0;
         bool in_macro = false, interacted = false;
-        if (state == WS_READY) {
-            const int info = sh.res_info[lane];
-            const double distance = sh.d_boundary[lane];
-            const int code = info & 7;
-            if (!(info & 8)) p.next_line_id = sh.res_line[lane];
-            if (code == 4) err = ERR_MONTECARLO;
-            type = code == 1 ? IT_BOUNDARY : (code == 2 ? IT_ESCATTERING : IT_LINE);
-            if (!err) {
-                // move_r_packet + update_estimators_bulk (packets/movement.py:31-76)
-                const double r = p.r;
-                if (distance > 0.0) {
-                    const double new_r = sqrt(r * r + distance * distance + 2.0 * r * distance * p.mu);
-                    const double mu_new = (p.mu * r + distance) / new_r;
-                    const double comov_nu = p.nu * dop;
-                    const double comov_energy = p.energy * dop;
-                    const double dist_est = FULL ? distance * dop : distance;
-                    if (!(P.debug_flags & 2)) {
-                        atomicAdd(&lds_J[p.shell], comov_energy * dist_est);
-                        atomicAdd(&lds_nubar[p.shell], comov_energy * dist_est * comov_nu);
-                    }
-                    p.mu = mu_new;
-                    p.r = new_r;
-                }
-                if (type == IT_BOUNDARY) {
-                    if (TRACK) trk.boundary_buffer[lane] += 1;
-                    cross_shell(p.shell, p.status, ((pflags >> 1) & 3) - 1, P.n_shells);
-                } else {
-                    interacted = true;
-                    before_nu = p.nu; before_mu = p.mu; before_energy = p.energy;
-                    absorb = (type == IT_LINE) ? p.next_line_id : -1;
-                    // common part of line_scatter_event (interaction_event_callers.py:187-239) and thomson_scatter
-                    // (interaction_events.py:184-217): Doppler with the old angle, new isotropic angle, Doppler back
-                    const double vel = p.r / t;
-                    const double old_dop = doppler_factor<FULL>(vel, p.mu);
-                    scat_comov_nu = p.nu * old_dop;
-                    const double comov_energy = p.energy * old_dop;
-                    p.mu = 2.0 * draw() - 1.0;
-                    inv_new = inverse_doppler_factor<FULL>(vel, p.mu);
-                    p.energy = comov_energy * inv_new;
-                    if (type == IT_LINE) {
-                        emit = p.next_line_id;
-                        if (P.line_interaction_type != 0) {
-                            const int2 blk = P.line_block[(unsigned)p.next_line_id];
-                            mb0 = blk.x; mb1 = blk.y;
-                            in_macro = true;
+        // ---- log the line visits of the finished traces (update_line_estimators, deferred: estimator_log.hpp)
+        {
+            int n_visit = 0, start = 0;
+            if (ready) {
+                const int info = sh.res_info[lane];
+                distance = sh.d_boundary[lane];
+                const int code = info & 7;
+                start = p.next_line_id;
+                const int stop_line = (info & 8) ? L : sh.res_line[lane];
+                n_visit = stop_line - start + ((code == 3) ? 1 : 0);
+                if (!(info & 8)) p.next_line_id = stop_line;
+                if (code == 4) err = ERR_MONTECARLO;
+                type = code == 1 ? IT_BOUNDARY : (code == 2 ? IT_ESCATTERING : IT_LINE);
+                if (P.debug_flags & 1) n_visit = 0;
+            }
+            // the 64 log slots of this pass were reserved during the previous one (the returning atomic's latency is
+            // hidden behind a whole sweep phase); lanes without a record mark their slot as empty
+            if (__ballot(ready)) {
+                const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)log_next);
+                const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(log_next >> 32));
+                const unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)lane;
+                if (lane == 0) log_next = atomicAdd(log.cursor, 64ull);
+                if (n_visit > 0) {
+                    LineVisitRecord rec;
+                    rec.energy = p.energy; rec.nu = p.nu; rec.comov_nu = p.nu * dop; rec.mur = p.mu * p.r;
+                    rec.idx0 = (unsigned)p.shell * (unsigned)L + (unsigned)start;
+                    rec.n_flags = (unsigned)n_visit | ((unsigned)(pflags & 1) << 31);
+                    rec.pad[0] = rec.pad[1] = 0;
+                    if (slot < log.capacity) {
+                        log.records[slot] = rec;
+                        log.keys[slot] = (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE);
+                    } else {  // log full: add the terms directly (slow, only when the host under-sized the log)
+                        const bool fast = (pflags & 1) != 0;
+                        const double rcp_nu = 1.0 / rec.nu;
+                        for (int k = 0; k < n_visit; ++k) {
+                            double e_term, jb_term;
+                            line_estimator_terms<FULL>(rec, fast, rcp_nu, P.nu_line[(unsigned)(start + k)], t, P.tc, P.rcp_tc, e_term, jb_term);
+                            atomic_add_f64(&jb[rec.idx0 + (unsigned)k], jb_term);
+                            atomic_add_f64(&ed[rec.idx0 + (unsigned)k], e_term);
                         }
+                    }
+                } else if (slot < log.capacity) log.keys[slot] = (unsigned)log.empty_bin;
+            }
+        }
+        // ---- epilogue of the finished traces: move, estimators, boundary / scattering
+        if (ready && !err) {
+            // move_r_packet + update_estimators_bulk (packets/movement.py:31-76)
+            const double r = p.r;
+            if (distance > 0.0) {
+                const double new_r = sqrt(r * r + distance * distance + 2.0 * r * distance * p.mu);
+                const double mu_new = (p.mu * r + distance) / new_r;
+                const double comov_nu = p.nu * dop;
+                const double comov_energy = p.energy * dop;
+                const double dist_est = FULL ? distance * dop : distance;
+                if (!(P.debug_flags & 2)) {
+                    atomicAdd(&lds_J[p.shell], comov_energy * dist_est);
+                    atomicAdd(&lds_nubar[p.shell], comov_energy * dist_est * comov_nu);
+                }
+                p.mu = mu_new;
+                p.r = new_r;
+            }
+            if (type == IT_BOUNDARY) {
+                if (TRACK) trk_boundary += 1;
+                cross_shell(p.shell, p.status, ((pflags >> 1) & 3) - 1, P.n_shells);
+            } else {
+                interacted = true;
+                if (TRACK) {
+                    trk.before_nu[lane] = p.nu; trk.before_mu[lane] = p.mu; trk.before_energy[lane] = p.energy;
+                    trk.line_absorb_id[lane] = (type == IT_LINE) ? p.next_line_id : -1;
+                    trk.radius[lane] = p.r; trk.shell_id[lane] = p.shell; trk.interaction_type[lane] = type;
+                }
+                // common part of line_scatter_event (interaction_event_callers.py:187-239) and thomson_scatter
+                // (interaction_events.py:184-217): Doppler with the old angle, new isotropic angle, Doppler back
+                const double vel = p.r / t;
+                const double old_dop = doppler_factor<FULL>(vel, p.mu);
+                const double scat_comov_nu = p.nu * old_dop;
+                const double comov_energy = p.energy * old_dop;
+                p.mu = 2.0 * draw() - 1.0;
+                inv_new = inverse_doppler_factor<FULL>(vel, p.mu);
+                p.energy = comov_energy * inv_new;
+                if (type != IT_LINE) p.nu = scat_comov_nu * inv_new;
+                if (type == IT_LINE) {
+                    emit = p.next_line_id;
+                    if (P.line_interaction_type != 0) {
+                        const int2 blk = P.line_block[(unsigned)p.next_line_id];
+                        mb0 = blk.x; mb1 = blk.y;
+                        in_macro = true;
                     }
                 }
             }
         }
         // ---- macro_atom_interaction (macro_atom.py:52-104), one jump per pass, lane-per-packet
         while (__ballot(in_macro)) {
-            refill(__ballot(in_macro && r_cnt < 1));
+            refill(__ballot(in_macro && r_cnt < 2), seeded_states);
             if (in_macro) {
                 const unsigned row = (unsigned)p.shell * (unsigned)P.n_trans;
                 const double event = draw();
@@ -333,25 +377,21 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_
             }
         }
         // ---- finish the interaction, hand finished packets over
-        if (state == WS_READY) {
+        if (ready) {
             if (interacted && !err) {
                 int emit_id = -1;
                 if (type == IT_LINE) {  // line_emission (interaction_events.py:227-258); its inverse Doppler factor == inv_new
                     p.nu = P.nu_line[emit] * inv_new;
                     p.next_line_id = emit + 1;
                     emit_id = emit;
-                } else {
-                    p.nu = scat_comov_nu * inv_new;
                 }
                 if (FULL) p.mu = aberration_cmf_to_lf(p.r, t, p.mu);
                 if (TRACK) {
-                    trk.before_nu[lane] = before_nu; trk.before_mu[lane] = before_mu; trk.before_energy[lane] = before_energy;
-                    trk.line_absorb_id[lane] = absorb; trk.line_emit_id[lane] = emit_id;
+                    trk.line_emit_id[lane] = emit_id;
                     trk.after_mu[lane] = p.mu;
-                    trk.interactions_count[lane] += 1 + trk.boundary_buffer[lane];
-                    trk.boundary_buffer[lane] = 0;
-                    trk.radius[lane] = p.r; trk.shell_id[lane] = p.shell;
-                    trk.interaction_type[lane] = type;
+                    trk_count += 1 + trk_boundary;
+                    trk_boundary = 0;
+                    trk_any = true;
                 }
             }
             state = WS_NEED_TRACE;
@@ -367,7 +407,7 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_
                     C->out_nu[i] = p.nu;
                     C->out_e[i] = (p.status == ST_REABSORBED) ? -p.energy : p.energy;
                     if (TRACK) {
-                        const bool any = trk.interaction_type[lane] >= 0;
+                        const bool any = trk_any;
                         const double nan = __builtin_nan("");
                         C->li_radius[i] = any ? trk.radius[lane] : nan;
                         C->li_nu[i] = any ? p.nu : nan;
@@ -378,9 +418,11 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_
                         C->li_after_nu[i] = any ? p.nu : nan;
                         C->li_after_mu[i] = any ? trk.after_mu[lane] : nan;
                         C->li_after_energy[i] = any ? p.energy : nan;
-                        C->li_shell_id[i] = trk.shell_id[lane]; C->li_interaction_type[i] = trk.interaction_type[lane];
-                        C->li_line_absorb_id[i] = trk.line_absorb_id[lane]; C->li_line_emit_id[i] = trk.line_emit_id[lane];
-                        C->li_interactions_count[i] = trk.interactions_count[lane];
+                        C->li_shell_id[i] = any ? trk.shell_id[lane] : -1;
+                        C->li_interaction_type[i] = any ? trk.interaction_type[lane] : -1;
+                        C->li_line_absorb_id[i] = any ? trk.line_absorb_id[lane] : -1;
+                        C->li_line_emit_id[i] = any ? trk.line_emit_id[lane] : -1;
+                        C->li_interactions_count[i] = trk_count;
                     }
                 }
                 state = WS_NEED_PACKET;
@@ -410,11 +452,7 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_
                         const DeviceProblem *C = P.cold;
                         p.r = C->r0[i]; p.mu = C->mu0[i]; p.nu = C->nu0[i]; p.energy = C->e0[i];
                         p.shell = 0; p.status = ST_IN_PROCESS;
-                        if (TRACK) {
-                            trk.shell_id[lane] = -1; trk.interaction_type[lane] = -1; trk.line_absorb_id[lane] = -1;
-                            trk.line_emit_id[lane] = -1; trk.interactions_count[lane] = 0;
-                            trk.boundary_buffer[lane] = 0;  // -1 + the initial track_boundary_event
-                        }
+                        if (TRACK) { trk_count = 0; trk_boundary = 0; trk_any = false; }  // (-1 + the initial track_boundary_event)
                         {   // set_packet_props_{partial,full}_relativity (classic/packet_propagation.py:254-318)
                             const double velocity = p.r / t;
                             const double inv = inverse_doppler_factor<FULL>(velocity, p.mu);
@@ -446,90 +484,102 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_
         }
         if (__ballot(state != WS_DONE) == 0ull) break;
         // ---- prologue of the next trace (trace_packet, modes/homologous_rad_packet_transport.py:30-98)
-        refill(__ballot(state == WS_NEED_TRACE && r_cnt < 1));
-        if (state == WS_NEED_TRACE) {
-            const double velocity = p.r / t;
-            dop = doppler_factor<FULL>(velocity, p.mu);
-            double chi_e = P.n_e[p.shell] * P.sigma_thomson;
-            if (FULL) chi_e *= dop;
-            double d_boundary;
-            int delta;
-            distance_boundary(p.r, p.mu, P.r_inner[p.shell], P.r_outer[p.shell], d_boundary, delta);
-            const double tau_event = -mcm::log(draw());
-            const double comov_nu = p.nu * dop;
-            ++events;
-            const bool fast = mid_range(p.nu) && mid_range(chi_e) && mid_range(tau_event) && mid_range(p.energy) &&
-                              mid_range(p.r) && mid_range(comov_nu) && mid_range(P.t_exp) && !(P.debug_flags & 4);
-            pflags = (fast ? 1 : 0) | ((delta + 1) << 1);
-            sh.comov_nu[lane] = comov_nu; sh.chi[lane] = chi_e; sh.tau_event[lane] = tau_event; sh.d_boundary[lane] = d_boundary;
-            sh.rcp_nu[lane] = 1.0 / p.nu; sh.rcp_chi[lane] = 1.0 / chi_e; sh.mur[lane] = p.mu * p.r;
-            sh.res_info[lane] = RES_PENDING;
-            state = WS_POOL;
+        refill(__ballot(state == WS_NEED_TRACE && r_cnt < 1), seeded_states);
+        {
+            const bool go = state == WS_NEED_TRACE;
+            if (go) {
+                const double velocity = p.r / t;
+                dop = doppler_factor<FULL>(velocity, p.mu);
+                double chi_e = P.n_e[p.shell] * P.sigma_thomson;
+                if (FULL) chi_e *= dop;
+                double d_boundary;
+                int delta;
+                distance_boundary(p.r, p.mu, P.r_inner[p.shell], P.r_outer[p.shell], d_boundary, delta);
+                const double tau_event = -mcm::log(draw());
+                const double comov_nu = p.nu * dop;
+                ++events;
+                const bool fast = mid_range(p.nu) && mid_range(chi_e) && mid_range(tau_event) && mid_range(p.energy) &&
+                                  mid_range(p.r) && mid_range(comov_nu) && mid_range(P.t_exp) && !(P.debug_flags & 4);
+                pflags = (fast ? 1 : 0) | ((delta + 1) << 1);
+                sh.nu[lane] = p.nu; sh.rcp_nu[lane] = 1.0 / p.nu; sh.comov_nu[lane] = comov_nu;
+                sh.chi[lane] = chi_e; sh.rcp_chi[lane] = 1.0 / chi_e;
+                sh.tau_event[lane] = tau_event; sh.d_boundary[lane] = d_boundary;
+                if (FULL) { shf.r[lane] = p.r; shf.mu[lane] = p.mu; }
+                sh.cursor[lane] = p.next_line_id;
+                sh.rowfast[lane] = (int)(((unsigned)p.shell * (unsigned)L) | (fast ? 0x80000000u : 0u));
+                state = WS_SWEEP;
+            }
+            const unsigned long long go_mask = __ballot(go);
+            if (go) sh.queue[(q_tail + __popcll(go_mask & ((1ull << lane) - 1ull))) & 63] = lane;
+            q_tail += __popcll(go_mask);
         }
 
-        // ============================================================ sweep phase (G-lane groups work off the pool)
+        // ============================================================ sweep phase (G-lane groups work off the queue)
+        // worker state of this lane's group; every group is idle again when the phase ends
+        SweepSlot cur;
+        cur.owner = -1; cur.cur0 = 0; cur.row = 0; cur.fast = true;
+        cur.nu = cur.rcp_nu = cur.comov_nu = cur.chi = cur.rcp_chi = cur.tau_event = cur.d_boundary = cur.r = cur.mu = 0.0;
+        cur.tau_carry = cur.d_cont_carry = cur.nu_line = cur.tau_line = 0.0;
+        int nxt_owner = -1, n_cursor = 0;
+        unsigned n_rowfast = 0;
+        double n_nu = 0.0, n_tau = 0.0;
+        // The phase ends when every prepared trace has been swept.  (Ending it earlier, as soon as most lanes have their
+        // result, and letting the long sweeps run on across event phases was measured: fewer but fuller steps, more event
+        // phases, no gain.)
         for (;;) {
-            unsigned long long pool = __ballot(state == WS_POOL);
+            const int avail = q_tail - q_head;
             const unsigned long long busy = __ballot(cur.owner >= 0 || nxt_owner >= 0);
-            if (!pool && !busy) break;
+            if (avail == 0 && !busy) break;
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): everything prefetched during the previous step has landed
-            // ---- a group whose sweep ended continues with the packet it prefetched
-            const bool promote = cur.owner < 0 && nxt_owner >= 0;
-            if (__ballot(promote)) {
-                const int src = nxt_owner >= 0 ? nxt_owner : lane;
-                const double f_nu = __shfl(p.nu, src), f_energy = __shfl(p.energy, src);
-                const double f_r = FULL ? __shfl(p.r, src) : 0.0, f_mu = FULL ? __shfl(p.mu, src) : 0.0;
-                const int f_flags = __shfl(pflags, src);
-                if (promote) {
-                    cur.owner = nxt_owner;
-                    nxt_owner = -1;
-                    cur.nu = f_nu; cur.energy = f_energy; cur.r = f_r; cur.mu = f_mu;
-                    cur.fast = (f_flags & 1) != 0;
-                    cur.comov_nu = sh.comov_nu[cur.owner]; cur.chi = sh.chi[cur.owner]; cur.tau_event = sh.tau_event[cur.owner];
-                    cur.d_boundary = sh.d_boundary[cur.owner]; cur.rcp_nu = sh.rcp_nu[cur.owner]; cur.rcp_chi = sh.rcp_chi[cur.owner];
-                    cur.mur = sh.mur[cur.owner];
-                    cur.cur0 = n_cursor; cur.row = n_row;
-                    cur.nu_line = n_nu; cur.tau_line = n_tau;
-                    cur.tau_carry = 0.0;
-                    cur.d_cont_carry = cur.fast ? exact_div<true>(cur.tau_event, cur.chi, cur.rcp_chi)
-                                                : exact_div<false>(cur.tau_event, cur.chi, cur.rcp_chi);
-                    cur.pend_valid = false;
-                }
+            ++dbg_rounds;
+            // ---- a group whose sweep ended continues with the trace whose first lines it prefetched
+            if (cur.owner < 0 && nxt_owner >= 0) {
+                const int o = nxt_owner;
+                cur.owner = o;
+                nxt_owner = -1;
+                cur.nu = sh.nu[o]; cur.rcp_nu = sh.rcp_nu[o]; cur.comov_nu = sh.comov_nu[o];
+                cur.chi = sh.chi[o]; cur.rcp_chi = sh.rcp_chi[o]; cur.tau_event = sh.tau_event[o]; cur.d_boundary = sh.d_boundary[o];
+                if (FULL) { cur.r = shf.r[o]; cur.mu = shf.mu[o]; }
+                cur.fast = (n_rowfast >> 31) != 0;
+                cur.cur0 = n_cursor; cur.row = n_rowfast & 0x7fffffffu;
+                cur.nu_line = n_nu; cur.tau_line = n_tau;
+                cur.tau_carry = 0.0;
+                cur.d_cont_carry = cur.fast ? exact_div<true>(cur.tau_event, cur.chi, cur.rcp_chi)
+                                            : exact_div<false>(cur.tau_event, cur.chi, cur.rcp_chi);
             }
-            // ---- hand waiting packets to the groups without a prefetched one and start loading their first lines
-            unsigned long long free_groups = __ballot(nxt_owner < 0 && j == 0);
-            if (pool && free_groups) {
-                bool newly = false;
-                while (pool && free_groups) {
-                    const int gl = __builtin_ctzll(free_groups);
-                    const int o = __builtin_ctzll(pool);
-                    free_groups &= free_groups - 1;
-                    pool &= pool - 1;
-                    if (group_lane0 == gl) { nxt_owner = o; newly = true; }
-                    if (lane == o) state = WS_ASSIGNED;
-                }
-                const int src = nxt_owner >= 0 ? nxt_owner : lane;
-                const int f_line = __shfl(p.next_line_id, src), f_shell = __shfl(p.shell, src);
-                if (newly) {
-                    n_cursor = f_line;
-                    n_row = (unsigned)f_shell * (unsigned)L;
-                    const int line = n_cursor + j;
-                    const bool in = line < L;
-                    n_nu = in ? P.nu_line[(unsigned)line] : 0.0;
-                    n_tau = in ? P.tau_t[n_row + (unsigned)line] : 0.0;
+            // ---- hand waiting traces to the groups without a prefetched one and start loading their first lines
+            {
+                const unsigned long long free_groups = __ballot(nxt_owner < 0 && j == 0);
+                if (avail > 0 && free_groups) {
+                    const int rank = __popcll(free_groups & ((1ull << group_lane0) - 1ull));
+                    if (nxt_owner < 0 && rank < avail) {
+                        nxt_owner = sh.queue[(q_head + rank) & 63];
+                        n_cursor = sh.cursor[nxt_owner];
+                        n_rowfast = (unsigned)sh.rowfast[nxt_owner];
+                        const int line = n_cursor + j;
+                        const bool in = line < L;
+                        n_nu = in ? H.nu_line[(unsigned)line] : 0.0;
+                        n_tau = in ? H.tau_t[(n_rowfast & 0x7fffffffu) + (unsigned)line] : 0.0;
+                    }
+                    q_head += min(__popcll(free_groups), avail);
                 }
             }
             // ---- one G-line step of every running sweep
             if (cur.owner >= 0) {
-                if (cur.fast) sweep_step<FULL, G, true>(P, cur, j, jb, ed, sh, visits);
-                else sweep_step<FULL, G, false>(P, cur, j, jb, ed, sh, visits);
+                if (cur.fast) sweep_step<FULL, G, true>(H, cur, j, sh, visits);
+                else sweep_step<FULL, G, false>(H, cur, j, sh, visits);
             }
-            if (state == WS_ASSIGNED && sh.res_info[lane] != RES_PENDING) state = WS_READY;
         }
     }
 
-    const DeviceProblem *C = P.cold;
-    for (int s = lane; s < P.n_shells; s += 64) {
+    {   // the slots reserved for a pass that never came
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)log_next);
+        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(log_next >> 32));
+        const unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)lane;
+        if (slot < W->log.capacity) W->log.keys[slot] = (unsigned)W->log.empty_bin;
+    }
+    const DeviceProblem *C = W->P.cold;
+    for (int s = lane; s < H.n_shells; s += 64) {
         if (lds_J[s] != 0.0) atomic_add_f64(&C->J[s], lds_J[s]);
         if (lds_nubar[s] != 0.0) atomic_add_f64(&C->nubar[s], lds_nubar[s]);
     }
@@ -544,6 +594,7 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(GroupArgs P, uint32_
         atomicAdd(&C->counters[1], e);
         atomicAdd(&C->counters[2], m);
         atomicAdd(&C->counters[5], d);
+        if (H.debug_flags & 16) atomicAdd(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
     }
 }
 

@@ -20,6 +20,7 @@
 #include "mc_device.hpp"
 #include "propagate_lane.hpp"
 #include "propagate_group.hpp"
+#include "estimator_log.hpp"
 #include "propagate_wave.hpp"
 #include "packet_source.hpp"
 
@@ -121,10 +122,13 @@ struct TardisMcContext {
     mc::DeviceProblem problem_host{};
     long long chunk_packets = 16LL << 20;  // packets per seeded-state chunk (2496 B each) of the cooperative kernel
     // launch geometry
-    int variant = 1;  // 0: lane-per-packet kernel; 1: cooperative 16-lanes-per-packet kernel (v-packets fall back to 0)
+    int variant = 2;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel (v-packets: variant 1)
     int blocks_per_cu = 16;
     int debug_flags = 0;
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
+    long long log_capacity = 500000000LL;  // line-visit records per chunk of the wave kernel (48 B + 8 B each)
+    DevBuf log_records, log_keys, log_cursor, log_bins, log_sorted, tracker_scratch, wave_cold_dev;
+    std::vector<mc::WaveCold> wave_cold_host;
     int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
     // RCCL
     void *comm = nullptr;
@@ -515,7 +519,8 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vpacket_log_capacity") ctx->vlog_capacity = value;
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
-    else if (n == "group_size") ctx->group_size = (value == 8) ? 8 : (value == 16 ? 16 : 0);
+    else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
+    else if (n == "log_capacity") ctx->log_capacity = std::max<long long>(0, value);
     else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
     else return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return TARDIS_MC_OK;
@@ -976,7 +981,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         const bool full = c.enable_full_relativity != 0, trk = ctx->track;
         // variant 2: wave-owner kernel (lane-per-packet event code, groups as sweep workers); no v-packets yet
         const bool wave_kernel = ctx->variant == 2 && !vpk;
-        const size_t wave_lds = trk ? mc::wave_kernel_lds_bytes<true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false>(ctx->n_shells);
+        const size_t wave_lds = full ? mc::wave_kernel_lds_bytes<true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false>(ctx->n_shells);
         if (wave_kernel && wave_lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
         const int wave_waves_per_cu = std::max(1, std::min(ctx->waves_per_simd > 0 ? 4 * ctx->waves_per_simd : 16, (int)((160 * 1024) / wave_lds)));
 #define TMC_PICK2(G_, V_) (full ? (trk ? mc::propagate_group_kernel<true, true, G_, 256, 4, V_> : mc::propagate_group_kernel<true, false, G_, 256, 4, V_>) \
@@ -984,10 +989,34 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         if (G == 16) k = vpk ? TMC_PICK2(16, true) : TMC_PICK2(16, false);
         else k = vpk ? TMC_PICK2(8, true) : TMC_PICK2(8, false);
 #undef TMC_PICK2
+        using WaveKernelFn = void (*)(mc::WaveHot, const mc::WaveCold *);
+        WaveKernelFn kw = nullptr;
 #define TMC_PICKW(G_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_> : mc::propagate_wave_kernel<true, false, G_>) \
                             : (trk ? mc::propagate_wave_kernel<false, true, G_> : mc::propagate_wave_kernel<false, false, G_>))
-        if (wave_kernel) k = (G == 16) ? TMC_PICKW(16) : TMC_PICKW(8);
+        if (wave_kernel) kw = (ctx->group_size == 16) ? TMC_PICKW(16) : (ctx->group_size == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
 #undef TMC_PICKW
+        // estimator log of the wave kernel (estimator_log.hpp)
+        mc::EstimatorLog elog{};
+        int n_bins = 0;
+        if (wave_kernel) {
+            const int tiles = (ctx->n_lines + mc::EST_TILE - 1) / mc::EST_TILE;
+            n_bins = ctx->n_shells * std::max(tiles, 1);
+            unsigned long long cap = (unsigned long long)ctx->log_capacity;
+            if (n_bins + 1 > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernel adds its terms directly
+            cap = std::min<unsigned long long>(cap, 0xfffffff0ull);
+            HIP_TRY(ctx, ctx->log_records.ensure(std::max<size_t>(cap, 1) * sizeof(mc::LineVisitRecord)));
+            HIP_TRY(ctx, ctx->log_keys.ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
+            HIP_TRY(ctx, ctx->log_sorted.ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
+            HIP_TRY(ctx, ctx->log_cursor.ensure(sizeof(unsigned long long)));
+            HIP_TRY(ctx, ctx->log_bins.ensure((size_t)(4 * (n_bins + 2)) * sizeof(unsigned)));
+            elog.records = ctx->log_records.as<mc::LineVisitRecord>();
+            elog.keys = ctx->log_keys.as<unsigned>();
+            elog.cursor = ctx->log_cursor.as<unsigned long long>();
+            elog.capacity = cap;
+            elog.tiles_per_shell = std::max(tiles, 1);
+            elog.empty_bin = n_bins;
+            n_bins += 1;  // + the bin of reserved but unused log slots
+        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
         ctx->chunks_timed = 0;
         for (long long first = 0; first < ctx->n_packets; first += chunk) {
@@ -1010,7 +1039,45 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             if (wave_kernel) {
                 const long long want_waves = (count + 63) / 64;
                 const int waves = (int)std::max<long long>(1, std::min<long long>(want_waves, (long long)cus * wave_waves_per_cu));
-                hipLaunchKernelGGL(k, dim3(waves), dim3(64), wave_lds, ctx->stream, P, ctx->seeded_states.as<uint32_t>(), first, count);
+                HIP_TRY(ctx, hipMemsetAsync(ctx->log_cursor.p, 0, sizeof(unsigned long long), ctx->stream));
+                HIP_TRY(ctx, ctx->tracker_scratch.ensure((trk ? (size_t)waves : 1) * sizeof(mc::WaveTracker)));
+                // cold arguments of this launch: one device slot per chunk (the host copies stay alive in ctx->wave_cold_host)
+                const int ci_w = ctx->chunks_timed;
+                if ((int)ctx->wave_cold_host.size() <= ci_w) ctx->wave_cold_host.resize(ci_w + 1);
+                HIP_TRY(ctx, ctx->wave_cold_dev.ensure((size_t)(ci_w + 1) * sizeof(mc::WaveCold)));
+                mc::WaveCold &wc = ctx->wave_cold_host[ci_w];
+                wc.P = P; wc.log = elog; wc.seeded_states = ctx->seeded_states.as<uint32_t>();
+                wc.tracker_scratch = ctx->tracker_scratch.as<mc::WaveTracker>();
+                wc.chunk_first = first; wc.chunk_count = count;
+                mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci_w;
+                HIP_TRY(ctx, hipMemcpyAsync(wc_dev, &wc, sizeof(mc::WaveCold), hipMemcpyHostToDevice, ctx->stream));
+                mc::WaveHot hot{};
+                hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
+                hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
+                hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
+                hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, ctx->stream, hot, (const mc::WaveCold *)wc_dev);
+                HIP_TRY(ctx, hipGetLastError());
+                if (elog.capacity > 0) {
+                    unsigned *bin_count = ctx->log_bins.as<unsigned>(), *bin_start = bin_count + (n_bins + 1),
+                             *bin_fill = bin_start + (n_bins + 1), *slice_start = bin_fill + (n_bins + 1);
+                    HIP_TRY(ctx, hipMemsetAsync(bin_count, 0, (size_t)(n_bins + 1) * sizeof(unsigned), ctx->stream));
+                    const size_t hist_lds = (size_t)n_bins * sizeof(unsigned);
+                    const int bin_blocks = cus * 4;
+                    hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, ctx->stream, elog.keys, elog.cursor,
+                                       elog.capacity, n_bins, bin_count);
+                    hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, bin_count, n_bins, bin_start, bin_fill, slice_start);
+                    hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, ctx->stream, elog.keys, elog.cursor,
+                                       elog.capacity, n_bins, bin_fill, ctx->log_sorted.as<unsigned>());
+                    const unsigned acc_blocks = (unsigned)(cus * 5);
+                    if (full)
+                        hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(256), 0, ctx->stream, elog.records,
+                                           ctx->log_sorted.as<unsigned>(), bin_start, slice_start, n_bins - 1, elog.tiles_per_shell, ctx->n_lines,
+                                           P.nu_line, P.t_exp, P.tc, P.rcp_tc, P.jblue_t, P.edot_t);
+                    else
+                        hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(256), 0, ctx->stream, elog.records,
+                                           ctx->log_sorted.as<unsigned>(), bin_start, slice_start, n_bins - 1, elog.tiles_per_shell, ctx->n_lines,
+                                           P.nu_line, P.t_exp, P.tc, P.rcp_tc, P.jblue_t, P.edot_t);
+                }
             } else
             hipLaunchKernelGGL(k, dim3(blocks), dim3(block), lds, ctx->stream, P, ctx->seeded_states.as<uint32_t>(), first, count);
             HIP_TRY(ctx, hipGetLastError());

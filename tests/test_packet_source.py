@@ -110,8 +110,9 @@ def test_device_source_feeds_transport_identically():
     assert np.array_equal(dev["packet_seeds"], pc.packet_seeds)
     eng.reset_estimators(); eng.propagate(); eng.synchronize()
     a = eng.get_results(track_last_interaction=False, want_line_estimators=False)
-    import dataclasses
-    pc2 = dataclasses.replace(pc, initial_nus=dev["initial_nus"].copy(), initial_mus=dev["initial_mus"].copy())
+    from tardis_amd import state as st
+    pc2 = st.PacketCollection(dev["initial_radii"], dev["initial_nus"], dev["initial_mus"], dev["initial_energies"],
+                              dev["packet_seeds"], pc.radiation_field_luminosity)
     eng.set_packets(pc2)
     eng.reset_estimators(); eng.propagate(); eng.synchronize()
     b = eng.get_results(track_last_interaction=False, want_line_estimators=False)

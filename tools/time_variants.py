@@ -1,0 +1,28 @@
+"""Time one propagate step for engine option combinations:  python tools/time_variants.py [config] key=value[,key=value...] ..."""
+import sys
+sys.path.insert(0, ".")
+from tardis_amd import synthetic
+from tardis_amd.engine import Engine
+
+cfg = int(sys.argv[1])
+kw = dict(synthetic.BASELINE_CONFIGS[cfg])
+if cfg >= 3:
+    kw["n_packets"] = 2_000_000
+prob = synthetic.make_problem(seed=1, **kw)
+for spec in sys.argv[2:]:
+    eng = Engine(0)
+    for kv in spec.split(","):
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+    eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+    best = None
+    for i in range(3):
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        ms = eng.last_propagate_ms()
+        best = ms if best is None else min(best, ms)
+    kt = eng.last_kernel_times()
+    cnt = eng.get_results(track_last_interaction=False, want_line_estimators=False).counters
+    print('   counters', cnt, flush=True)
+    print(f"{spec:50s} step {best:8.2f} ms  seed {kt['seed_ms']:.2f}  rest {kt['propagate_ms']:.2f}  -> {prob.packet_collection.number_of_packets / best / 1e3:.1f} Mpkt/s", flush=True)
+    eng.close()
