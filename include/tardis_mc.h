@@ -170,6 +170,9 @@ int tardis_mc_last_propagate_ms(TardisMcContext *ctx, double *out_ms);
 /* The same, split per kernel: total time of the MT19937 seeding launches and of the propagation launches of the last
  * tardis_mc_propagate, and how many propagation launches there were (packet chunks). */
 int tardis_mc_last_kernel_times(TardisMcContext *ctx, double *out_seed_ms, double *out_propagate_ms, int *out_launches);
+/* summed duration of the line-estimator passes (record binning + accumulation) of the last propagate call; 0 when the
+ * kernel variant in use updates the estimators with atomics */
+int tardis_mc_last_estimator_ms(TardisMcContext *ctx, double *out_ms);
 /* Per-packet results of the resident packets + estimators (re-laid to [L,S]) to caller memory. */
 int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *result);
 

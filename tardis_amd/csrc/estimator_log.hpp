@@ -158,9 +158,9 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const LineVisitRecord *
                                                          double *__restrict__ edot_t)
 {
     __shared__ double tile_jb[EST_TILE], tile_ed[EST_TILE];
-    __shared__ double st_energy[4][64], st_nu[4][64], st_rcp[4][64], st_cnu[4][64], st_mur[4][64];
-    __shared__ unsigned st_idx0[4][64], st_first[4][64];  // idx0 | fast << 31 is kept apart: st_fast
-    __shared__ unsigned char st_fast[4][64];
+    // staged records, array of structures: a lane fetches "its" record with three 16-byte LDS reads
+    struct __attribute__((aligned(16))) Staged { double energy, nu, rcp_nu, comov_nu, mur; unsigned idx0, first_fast; };
+    __shared__ Staged staged[4][64];
     __shared__ unsigned long long starts[4][EST_LONG + 1];
     const unsigned n_slices = slice_start[n_bins];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -221,21 +221,25 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const LineVisitRecord *
             const double rcp_nu = 1.0 / rec.nu;
             if (n) {  // staged in compacted order: the q-th record that starts is the q-th staged one
                 const int pos = __popcll(__ballot(true) & ((1ull << lane) - 1ull));
-                st_energy[w][pos] = rec.energy; st_nu[w][pos] = rec.nu; st_rcp[w][pos] = rcp_nu; st_cnu[w][pos] = rec.comov_nu;
-                st_mur[w][pos] = rec.mur; st_idx0[w][pos] = rec.idx0; st_first[w][pos] = excl; st_fast[w][pos] = fast ? 1 : 0;
+                Staged st;
+                st.energy = rec.energy; st.nu = rec.nu; st.rcp_nu = rcp_nu; st.comov_nu = rec.comov_nu; st.mur = rec.mur;
+                st.idx0 = rec.idx0; st.first_fast = excl | (fast ? 0x80000000u : 0u);
+                staged[w][pos] = st;
                 atomicOr(&starts[w][excl >> 6], 1ull << (excl & 63));
             }
+            const bool all_fast = __ballot(n != 0 && !fast) == 0ull;
             unsigned rec_base = 0;  // records started before this pass (wave-uniform)
             for (unsigned i = 0; i < n_pass; ++i) {
                 const unsigned long long m = starts[w][i];
                 const unsigned t = (i << 6) + (unsigned)lane;
                 if (t < total) {
                     const unsigned q = rec_base + (unsigned)__popcll(m & le_mask) - 1u;
-                    const unsigned idx = st_idx0[w][q] + (t - st_first[w][q]);
+                    const Staged st = staged[w][q];
+                    const unsigned idx = st.idx0 + (t - (st.first_fast & 0x7fffffffu));
                     const double nu_l = nu_line[idx - row];
                     double e_term, jb_term;
-                    if (st_fast[w][q]) accumulate_term<FULL, true>(st_energy[w][q], st_nu[w][q], st_rcp[w][q], st_cnu[w][q], st_mur[w][q], nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
-                    else accumulate_term<FULL, false>(st_energy[w][q], st_nu[w][q], st_rcp[w][q], st_cnu[w][q], st_mur[w][q], nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
+                    if (all_fast || (st.first_fast >> 31)) accumulate_term<FULL, true>(st.energy, st.nu, st.rcp_nu, st.comov_nu, st.mur, nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
+                    else accumulate_term<FULL, false>(st.energy, st.nu, st.rcp_nu, st.comov_nu, st.mur, nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
                     add_term(idx, jb_term, e_term);
                 }
                 rec_base += (unsigned)__popcll(m);

@@ -28,13 +28,14 @@
 
 namespace mc {
 
-constexpr int WV_RING = 8;  // look-ahead doubles per packet (power of two, >= 8: a refill adds 4)
+constexpr int WV_RING = 8;  // look-ahead doubles per packet (power of two; a refill adds 4, so it needs r_cnt <= 4).  16 with 8-double
+                            // refills was measured: fewer refill rounds, but the extra 4 KiB of LDS costs the 12th wave of the CU
 enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3 };
 constexpr int RES_PENDING = -1;
 
 // per-wave LDS, structure of arrays indexed by lane
 struct WaveShared {
-    double nu[64], rcp_nu[64], comov_nu[64], chi[64], rcp_chi[64], tau_event[64];
+    double nu[64], rcp_nu[64], comov_nu[64], chi[64], rcp_chi[64], tau_event[64], d_cont0[64];
     double d_boundary[64];  // in: boundary distance of the prepared trace; out: distance of the event found
     double ring[WV_RING][64];
     int cursor[64], rowfast[64];  // first line of the trace; shell * n_lines | exact-division fast path << 31
@@ -44,12 +45,11 @@ struct WaveShared {
 struct WaveSharedFull {  // only read by the full-relativity sweep
     double r[64], mu[64];
 };
-// Last-interaction tracker (packets/trackers/tracker_last_interaction.py:8-254): write-only until the packet ends, so it
-// lives in a global scratch slot of the wave (structure of arrays over the wave's lanes: every store is one coalesced
-// 256/512-byte write that stays in L2); nu/energy/after_nu/after_energy are the packet's final nu and energy.
-struct WaveTracker {
-    double radius[64], before_nu[64], before_mu[64], before_energy[64], after_mu[64];
-    int shell_id[64], line_absorb_id[64], line_emit_id[64], interaction_type[64];
+// Last-interaction tracker (packets/trackers/tracker_last_interaction.py:8-254), kept in the owner lane's registers;
+// nu/energy/after_nu/after_energy are the packet's final nu and energy.
+struct LaneTracker {
+    double radius, before_nu, before_mu, before_energy, after_mu;
+    int shell_id, line_absorb_id, line_emit_id, interaction_type;
 };
 
 template <bool FULL>
@@ -66,12 +66,10 @@ struct WaveHot {
     int n_lines, n_shells, disable_line_scattering, debug_flags;
     double t_exp, tc, rcp_tc;
 };
-struct WaveTracker;
 struct WaveCold {
     GroupArgs P;
     EstimatorLog log;
     uint32_t *seeded_states;
-    WaveTracker *tracker_scratch;
     long long chunk_first, chunk_count;
 };
 
@@ -95,9 +93,6 @@ __device__ __forceinline__ void sweep_step(const WaveHot &P, SweepSlot &s, const
     const int L = P.n_lines;
     const int gshift = (threadIdx.x & 63) & ~(G - 1);
     constexpr unsigned long long GMASK = (G == 16) ? 0xffffull : ((G == 8) ? 0xffull : 0xfull);
-    int info = 0, res_line = 0;
-    double distance = 0.0;
-    bool finished = false;
     if (s.cur0 < L) {
         const int line = s.cur0 + j;
         const bool in_range = line < L;
@@ -132,13 +127,13 @@ __device__ __forceinline__ void sweep_step(const WaveHot &P, SweepSlot &s, const
         const unsigned stop_mask = (unsigned)((__ballot(stop) >> gshift) & GMASK);
         if (stop_mask) {
             const int first = __builtin_ctz(stop_mask);
-            const int code = stop_b ? 1 : (stop_e ? 2 : (stop_l ? 3 : 4));
             visits += (unsigned long long)(first + 1);
-            finished = true;
-            info = gbcast<G>(code, first);
-            res_line = s.cur0 + first;
-            const double d_sel = stop_b ? s.d_boundary : (stop_e ? d_cont : d_trace);
-            distance = gbcast<G>(d_sel, first);
+            if (j == first) {  // the stopping lane hands the result to the owner lane
+                sh.d_boundary[s.owner] = stop_b ? s.d_boundary : (stop_e ? d_cont : d_trace);
+                sh.res_line[s.owner] = line;
+                sh.res_info[s.owner] = stop_b ? 1 : (stop_e ? 2 : (stop_l ? 3 : 4));
+            }
+            s.owner = -1;
         } else {
             const int n_in = min(G, L - s.cur0);
             visits += (unsigned long long)n_in;
@@ -150,22 +145,18 @@ __device__ __forceinline__ void sweep_step(const WaveHot &P, SweepSlot &s, const
         }
     } else {
         // for-else (lines 157-172): the line list is exhausted; next_line_id is left untouched (bit 3)
-        finished = true;
-        if (s.d_cont_carry < s.d_boundary) { distance = s.d_cont_carry; info = 2 | 8; }
-        else { distance = s.d_boundary; info = 1 | 8; }
-    }
-    if (finished) {
         if (j == 0) {
-            sh.d_boundary[s.owner] = distance;
-            sh.res_line[s.owner] = res_line;
-            sh.res_info[s.owner] = info;
+            const bool cont = s.d_cont_carry < s.d_boundary;
+            sh.d_boundary[s.owner] = cont ? s.d_cont_carry : s.d_boundary;
+            sh.res_line[s.owner] = 0;
+            sh.res_info[s.owner] = (cont ? 2 : 1) | 8;
         }
         s.owner = -1;
     }
 }
 
 template <bool FULL, bool TRACK, int G>
-__global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     WaveShared &sh = *reinterpret_cast<WaveShared *>(lds_raw);
@@ -190,6 +181,9 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const Wav
     int r_gpos = 0, r_head = 0, r_cnt = 0;  // MT19937: next state block to regenerate; LDS ring of tempered doubles
     unsigned draws = 0, events = 0, macro = 0;
     int trk_count = 0, trk_boundary = 0;  // interactions_count, boundary crossings since the last interaction
+    LaneTracker trk;
+    trk.radius = trk.before_nu = trk.before_mu = trk.before_energy = trk.after_mu = 0.0;
+    trk.shell_id = trk.line_absorb_id = trk.line_emit_id = trk.interaction_type = -1;
     bool trk_any = false;
     bool exhausted = false;  // wave-uniform: the chunk has no more packets
     int q_head = 0, q_tail = 0;  // wave-uniform: queue of prepared traces
@@ -225,7 +219,7 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const Wav
             const int src = my_owner >= 0 ? my_owner : lane;
             const int o_pkt = __shfl(pkt, src), o_gpos = __shfl(r_gpos, src), o_tail = __shfl((r_head + r_cnt) & (WV_RING - 1), src);
             if (my_owner >= 0) {
-                uint32_t *st = seeded_states + (size_t)o_pkt * MT_N;
+                uint32_t *st = seeded_states + (size_t)((H.debug_flags & 64) ? (o_pkt & 1023) : o_pkt) * MT_N;
                 const int k = o_gpos + sj;
                 const int k1 = (k + 1 == MT_N) ? 0 : k + 1;
                 const int km = (k + 397 >= MT_N) ? k + 397 - MT_N : k + 397;
@@ -251,7 +245,6 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const Wav
         const GroupArgs &P = W->P;
         const EstimatorLog &log = W->log;
         uint32_t *const seeded_states = W->seeded_states;
-        WaveTracker &trk = W->tracker_scratch[TRACK ? blockIdx.x : 0];
         const long long chunk_first = W->chunk_first, chunk_count = W->chunk_count;
         double *const jb = P.jblue_t, *const ed = P.edot_t;
         // every live packet gets the draws of one pass: new direction, first macro-atom jump, next tau_event
@@ -327,9 +320,9 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const Wav
             } else {
                 interacted = true;
                 if (TRACK) {
-                    trk.before_nu[lane] = p.nu; trk.before_mu[lane] = p.mu; trk.before_energy[lane] = p.energy;
-                    trk.line_absorb_id[lane] = (type == IT_LINE) ? p.next_line_id : -1;
-                    trk.radius[lane] = p.r; trk.shell_id[lane] = p.shell; trk.interaction_type[lane] = type;
+                    trk.before_nu = p.nu; trk.before_mu = p.mu; trk.before_energy = p.energy;
+                    trk.line_absorb_id = (type == IT_LINE) ? p.next_line_id : -1;
+                    trk.radius = p.r; trk.shell_id = p.shell; trk.interaction_type = type;
                 }
                 // common part of line_scatter_event (interaction_event_callers.py:187-239) and thomson_scatter
                 // (interaction_events.py:184-217): Doppler with the old angle, new isotropic angle, Doppler back
@@ -387,8 +380,8 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const Wav
                 }
                 if (FULL) p.mu = aberration_cmf_to_lf(p.r, t, p.mu);
                 if (TRACK) {
-                    trk.line_emit_id[lane] = emit_id;
-                    trk.after_mu[lane] = p.mu;
+                    trk.line_emit_id = emit_id;
+                    trk.after_mu = p.mu;
                     trk_count += 1 + trk_boundary;
                     trk_boundary = 0;
                     trk_any = true;
@@ -409,19 +402,19 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const Wav
                     if (TRACK) {
                         const bool any = trk_any;
                         const double nan = __builtin_nan("");
-                        C->li_radius[i] = any ? trk.radius[lane] : nan;
+                        C->li_radius[i] = any ? trk.radius : nan;
                         C->li_nu[i] = any ? p.nu : nan;
                         C->li_energy[i] = any ? p.energy : nan;
-                        C->li_before_nu[i] = any ? trk.before_nu[lane] : nan;
-                        C->li_before_mu[i] = any ? trk.before_mu[lane] : nan;
-                        C->li_before_energy[i] = any ? trk.before_energy[lane] : nan;
+                        C->li_before_nu[i] = any ? trk.before_nu : nan;
+                        C->li_before_mu[i] = any ? trk.before_mu : nan;
+                        C->li_before_energy[i] = any ? trk.before_energy : nan;
                         C->li_after_nu[i] = any ? p.nu : nan;
-                        C->li_after_mu[i] = any ? trk.after_mu[lane] : nan;
+                        C->li_after_mu[i] = any ? trk.after_mu : nan;
                         C->li_after_energy[i] = any ? p.energy : nan;
-                        C->li_shell_id[i] = any ? trk.shell_id[lane] : -1;
-                        C->li_interaction_type[i] = any ? trk.interaction_type[lane] : -1;
-                        C->li_line_absorb_id[i] = any ? trk.line_absorb_id[lane] : -1;
-                        C->li_line_emit_id[i] = any ? trk.line_emit_id[lane] : -1;
+                        C->li_shell_id[i] = any ? trk.shell_id : -1;
+                        C->li_interaction_type[i] = any ? trk.interaction_type : -1;
+                        C->li_line_absorb_id[i] = any ? trk.line_absorb_id : -1;
+                        C->li_line_emit_id[i] = any ? trk.line_emit_id : -1;
                         C->li_interactions_count[i] = trk_count;
                     }
                 }
@@ -504,9 +497,10 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const Wav
                 sh.nu[lane] = p.nu; sh.rcp_nu[lane] = 1.0 / p.nu; sh.comov_nu[lane] = comov_nu;
                 sh.chi[lane] = chi_e; sh.rcp_chi[lane] = 1.0 / chi_e;
                 sh.tau_event[lane] = tau_event; sh.d_boundary[lane] = d_boundary;
+                sh.d_cont0[lane] = tau_event / chi_e;  // distance_continuum in force at the first line
                 if (FULL) { shf.r[lane] = p.r; shf.mu[lane] = p.mu; }
                 sh.cursor[lane] = p.next_line_id;
-                sh.rowfast[lane] = (int)(((unsigned)p.shell * (unsigned)L) | (fast ? 0x80000000u : 0u));
+                sh.rowfast[lane] = (int)((((P.debug_flags & 32) ? 0u : (unsigned)p.shell) * (unsigned)L) | (fast ? 0x80000000u : 0u));
                 state = WS_SWEEP;
             }
             const unsigned long long go_mask = __ballot(go);
@@ -544,8 +538,7 @@ __global__ void __launch_bounds__(64) propagate_wave_kernel(WaveHot H, const Wav
                 cur.cur0 = n_cursor; cur.row = n_rowfast & 0x7fffffffu;
                 cur.nu_line = n_nu; cur.tau_line = n_tau;
                 cur.tau_carry = 0.0;
-                cur.d_cont_carry = cur.fast ? exact_div<true>(cur.tau_event, cur.chi, cur.rcp_chi)
-                                            : exact_div<false>(cur.tau_event, cur.chi, cur.rcp_chi);
+                cur.d_cont_carry = sh.d_cont0[o];
             }
             // ---- hand waiting traces to the groups without a prefetched one and start loading their first lines
             {

@@ -127,7 +127,13 @@ struct TardisMcContext {
     int debug_flags = 0;
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
     long long log_capacity = 500000000LL;  // line-visit records per chunk of the wave kernel (48 B + 8 B each)
-    DevBuf log_records, log_keys, log_cursor, log_bins, log_sorted, tracker_scratch, wave_cold_dev;
+    // wave kernel: chunks alternate between two buffer sets / streams, so that seeding and the estimator passes of one
+    // chunk overlap the propagation of its neighbours
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], seeded_states2, next_packet2, wave_cold_dev;
+    int pipeline_chunks = 1;  // >1: split a propagate call of the wave kernel into chunks on two streams (measured: a loss -- every chunk pays the drain of its last packets)
+    double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
     std::vector<mc::WaveCold> wave_cold_host;
     int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
     // RCCL
@@ -497,11 +503,19 @@ void tardis_mc_destroy(TardisMcContext *ctx)
                      &ctx->vlog_packet, &ctx->vlog_seq, &ctx->vlog_nu, &ctx->vlog_energy, &ctx->vlog_mu, &ctx->vlog_r,
                      &ctx->rng_state, &ctx->counters, &ctx->first_error, &ctx->next_packet, &ctx->seeded_states, &ctx->problem_dev};
     for (DevBuf *b : all) b->release();
+    for (int b = 0; b < 2; ++b) {
+        ctx->log_records[b].release(); ctx->log_keys[b].release(); ctx->log_cursor[b].release(); ctx->log_bins[b].release();
+        ctx->log_sorted[b].release();
+    }
+    ctx->seeded_states2.release(); ctx->next_packet2.release(); ctx->wave_cold_dev.release();
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -520,6 +534,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
+    else if (n == "pipeline_chunks") ctx->pipeline_chunks = std::max(1, (int)value);
     else if (n == "log_capacity") ctx->log_capacity = std::max<long long>(0, value);
     else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
     else return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
@@ -946,8 +961,24 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         }
     } else {
         // variant 1: cooperative kernel; MT19937 states are seeded per chunk by a lane-per-packet kernel
-        const long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
+        long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
+        const bool wave_kernel = ctx->variant == 2 && !vpk;  // wave-owner kernel (lane-per-packet event code, groups as sweep workers)
+        if (wave_kernel && ctx->pipeline_chunks > 1 && ctx->n_packets >= (2LL << 20)) {
+            // pipeline: ~pipeline_chunks chunks of at least 1 Mi packets, alternating between two streams
+            const long long want = (ctx->n_packets + ctx->pipeline_chunks - 1) / ctx->pipeline_chunks;
+            chunk = std::min(chunk, std::max<long long>(1LL << 20, (want + 65535) / 65536 * 65536));
+        }
+        const bool two_streams = wave_kernel && chunk < ctx->n_packets;
+        if (two_streams && !ctx->stream2) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
         HIP_TRY(ctx, ctx->seeded_states.ensure((size_t)chunk * mc::MT_N * sizeof(uint32_t)));
+        if (two_streams) {
+            HIP_TRY(ctx, ctx->seeded_states2.ensure((size_t)chunk * mc::MT_N * sizeof(uint32_t)));
+            HIP_TRY(ctx, ctx->next_packet2.ensure(sizeof(unsigned long long)));
+        }
         ctx->problem_host = make_device_problem(ctx);
         const mc::DeviceProblem &F = ctx->problem_host;
         HIP_TRY(ctx, ctx->problem_dev.ensure(sizeof(mc::DeviceProblem)));
@@ -979,8 +1010,6 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         using KernelFn = void (*)(mc::GroupArgs, uint32_t *, long long, long long);
         KernelFn k;
         const bool full = c.enable_full_relativity != 0, trk = ctx->track;
-        // variant 2: wave-owner kernel (lane-per-packet event code, groups as sweep workers); no v-packets yet
-        const bool wave_kernel = ctx->variant == 2 && !vpk;
         const size_t wave_lds = full ? mc::wave_kernel_lds_bytes<true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false>(ctx->n_shells);
         if (wave_kernel && wave_lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
         const int wave_waves_per_cu = std::max(1, std::min(ctx->waves_per_simd > 0 ? 4 * ctx->waves_per_simd : 16, (int)((160 * 1024) / wave_lds)));
@@ -1001,88 +1030,109 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         if (wave_kernel) {
             const int tiles = (ctx->n_lines + mc::EST_TILE - 1) / mc::EST_TILE;
             n_bins = ctx->n_shells * std::max(tiles, 1);
-            unsigned long long cap = (unsigned long long)ctx->log_capacity;
+            // the log must hold the traces of one chunk: ~64 per packet unless the caller says otherwise
+            unsigned long long cap = std::min<unsigned long long>((unsigned long long)ctx->log_capacity, (unsigned long long)chunk * 96ull + 65536ull);
             if (n_bins + 1 > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernel adds its terms directly
             cap = std::min<unsigned long long>(cap, 0xfffffff0ull);
-            HIP_TRY(ctx, ctx->log_records.ensure(std::max<size_t>(cap, 1) * sizeof(mc::LineVisitRecord)));
-            HIP_TRY(ctx, ctx->log_keys.ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
-            HIP_TRY(ctx, ctx->log_sorted.ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
-            HIP_TRY(ctx, ctx->log_cursor.ensure(sizeof(unsigned long long)));
-            HIP_TRY(ctx, ctx->log_bins.ensure((size_t)(4 * (n_bins + 2)) * sizeof(unsigned)));
-            elog.records = ctx->log_records.as<mc::LineVisitRecord>();
-            elog.keys = ctx->log_keys.as<unsigned>();
-            elog.cursor = ctx->log_cursor.as<unsigned long long>();
+            for (int b = 0; b < (two_streams ? 2 : 1); ++b) {
+                HIP_TRY(ctx, ctx->log_records[b].ensure(std::max<size_t>(cap, 1) * sizeof(mc::LineVisitRecord)));
+                HIP_TRY(ctx, ctx->log_keys[b].ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->log_sorted[b].ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->log_cursor[b].ensure(sizeof(unsigned long long)));
+                HIP_TRY(ctx, ctx->log_bins[b].ensure((size_t)(4 * (n_bins + 2)) * sizeof(unsigned)));
+            }
             elog.capacity = cap;
             elog.tiles_per_shell = std::max(tiles, 1);
             elog.empty_bin = n_bins;
             n_bins += 1;  // + the bin of reserved but unused log slots
         }
+        if (wave_kernel) {
+            const size_t n_chunks = (size_t)((ctx->n_packets + chunk - 1) / chunk) + 1;
+            HIP_TRY(ctx, ctx->wave_cold_dev.ensure(n_chunks * sizeof(mc::WaveCold)));
+            ctx->wave_cold_host.reserve(n_chunks);
+        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        if (two_streams) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        }
         ctx->chunks_timed = 0;
         for (long long first = 0; first < ctx->n_packets; first += chunk) {
             const long long count = std::min(chunk, ctx->n_packets - first);
             const int ci = ctx->chunks_timed;
-            while ((int)ctx->ev_chunk.size() < 3 * (ci + 1)) {
+            const int b = two_streams ? (ci & 1) : 0;
+            hipStream_t st = b ? ctx->stream2 : ctx->stream;
+            uint32_t *seeded = (b ? ctx->seeded_states2 : ctx->seeded_states).as<uint32_t>();
+            unsigned long long *next_packet = (b ? ctx->next_packet2 : ctx->next_packet).as<unsigned long long>();
+            while ((int)ctx->ev_chunk.size() < 4 * (ci + 1)) {
                 hipEvent_t e;
                 HIP_TRY(ctx, hipEventCreate(&e));
                 ctx->ev_chunk.push_back(e);
             }
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3 * ci], ctx->stream));
-            hipLaunchKernelGGL(mc::seed_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream,
-                               ctx->seeds.as<uint32_t>(), ctx->seeded_states.as<uint32_t>(), first, count);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci], st));
+            hipLaunchKernelGGL(mc::seed_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                               ctx->seeds.as<uint32_t>(), seeded, first, count);
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), ctx->stream));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3 * ci + 1], ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(next_packet, 0, sizeof(unsigned long long), st));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 1], st));
             const int groups_per_block = block / G;
             long long want_blocks = (count + groups_per_block - 1) / groups_per_block;
             int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)cus * blocks_per_cu));
             if (wave_kernel) {
                 const long long want_waves = (count + 63) / 64;
                 const int waves = (int)std::max<long long>(1, std::min<long long>(want_waves, (long long)cus * wave_waves_per_cu));
-                HIP_TRY(ctx, hipMemsetAsync(ctx->log_cursor.p, 0, sizeof(unsigned long long), ctx->stream));
-                HIP_TRY(ctx, ctx->tracker_scratch.ensure((trk ? (size_t)waves : 1) * sizeof(mc::WaveTracker)));
+                mc::EstimatorLog lg = elog;
+                lg.records = ctx->log_records[b].as<mc::LineVisitRecord>();
+                lg.keys = ctx->log_keys[b].as<unsigned>();
+                lg.cursor = ctx->log_cursor[b].as<unsigned long long>();
+                HIP_TRY(ctx, hipMemsetAsync(lg.cursor, 0, sizeof(unsigned long long), st));
                 // cold arguments of this launch: one device slot per chunk (the host copies stay alive in ctx->wave_cold_host)
-                const int ci_w = ctx->chunks_timed;
-                if ((int)ctx->wave_cold_host.size() <= ci_w) ctx->wave_cold_host.resize(ci_w + 1);
-                HIP_TRY(ctx, ctx->wave_cold_dev.ensure((size_t)(ci_w + 1) * sizeof(mc::WaveCold)));
-                mc::WaveCold &wc = ctx->wave_cold_host[ci_w];
-                wc.P = P; wc.log = elog; wc.seeded_states = ctx->seeded_states.as<uint32_t>();
-                wc.tracker_scratch = ctx->tracker_scratch.as<mc::WaveTracker>();
+                if ((int)ctx->wave_cold_host.size() <= ci) ctx->wave_cold_host.resize(ci + 1);
+                mc::WaveCold &wc = ctx->wave_cold_host[ci];
+                wc.P = P; wc.P.next_packet = next_packet; wc.log = lg; wc.seeded_states = seeded;
                 wc.chunk_first = first; wc.chunk_count = count;
-                mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci_w;
-                HIP_TRY(ctx, hipMemcpyAsync(wc_dev, &wc, sizeof(mc::WaveCold), hipMemcpyHostToDevice, ctx->stream));
+                mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci;
+                HIP_TRY(ctx, hipMemcpyAsync(wc_dev, &wc, sizeof(mc::WaveCold), hipMemcpyHostToDevice, st));
                 mc::WaveHot hot{};
                 hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
                 hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
                 hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
-                hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, ctx->stream, hot, (const mc::WaveCold *)wc_dev);
+                hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
                 HIP_TRY(ctx, hipGetLastError());
-                if (elog.capacity > 0) {
-                    unsigned *bin_count = ctx->log_bins.as<unsigned>(), *bin_start = bin_count + (n_bins + 1),
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));
+                if (lg.capacity > 0) {
+                    unsigned *bin_count = ctx->log_bins[b].as<unsigned>(), *bin_start = bin_count + (n_bins + 1),
                              *bin_fill = bin_start + (n_bins + 1), *slice_start = bin_fill + (n_bins + 1);
-                    HIP_TRY(ctx, hipMemsetAsync(bin_count, 0, (size_t)(n_bins + 1) * sizeof(unsigned), ctx->stream));
+                    unsigned *sorted = ctx->log_sorted[b].as<unsigned>();
+                    HIP_TRY(ctx, hipMemsetAsync(bin_count, 0, (size_t)(n_bins + 1) * sizeof(unsigned), st));
                     const size_t hist_lds = (size_t)n_bins * sizeof(unsigned);
                     const int bin_blocks = cus * 4;
-                    hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, ctx->stream, elog.keys, elog.cursor,
-                                       elog.capacity, n_bins, bin_count);
-                    hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, ctx->stream, bin_count, n_bins, bin_start, bin_fill, slice_start);
-                    hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, ctx->stream, elog.keys, elog.cursor,
-                                       elog.capacity, n_bins, bin_fill, ctx->log_sorted.as<unsigned>());
+                    hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.cursor, lg.capacity, n_bins, bin_count);
+                    hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_start, bin_fill, slice_start);
+                    hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.cursor, lg.capacity, n_bins,
+                                       bin_fill, sorted);
                     const unsigned acc_blocks = (unsigned)(cus * 5);
                     if (full)
-                        hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(256), 0, ctx->stream, elog.records,
-                                           ctx->log_sorted.as<unsigned>(), bin_start, slice_start, n_bins - 1, elog.tiles_per_shell, ctx->n_lines,
-                                           P.nu_line, P.t_exp, P.tc, P.rcp_tc, P.jblue_t, P.edot_t);
+                        hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(256), 0, st, lg.records, sorted, bin_start,
+                                           slice_start, n_bins - 1, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
+                                           P.jblue_t, P.edot_t);
                     else
-                        hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(256), 0, ctx->stream, elog.records,
-                                           ctx->log_sorted.as<unsigned>(), bin_start, slice_start, n_bins - 1, elog.tiles_per_shell, ctx->n_lines,
-                                           P.nu_line, P.t_exp, P.tc, P.rcp_tc, P.jblue_t, P.edot_t);
+                        hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(256), 0, st, lg.records, sorted, bin_start,
+                                           slice_start, n_bins - 1, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
+                                           P.jblue_t, P.edot_t);
                 }
-            } else
-            hipLaunchKernelGGL(k, dim3(blocks), dim3(block), lds, ctx->stream, P, ctx->seeded_states.as<uint32_t>(), first, count);
+            } else {
+                hipLaunchKernelGGL(k, dim3(blocks), dim3(block), lds, st, P, seeded, first, count);
+                HIP_TRY(ctx, hipGetLastError());
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));
+            }
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3 * ci + 2], ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 3], st));
             ctx->chunks_timed = ci + 1;
+        }
+        if (two_streams) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -1122,16 +1172,31 @@ int tardis_mc_last_kernel_times(TardisMcContext *ctx, double *out_seed_ms, doubl
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
         prop = ms;
     }
+    double post = 0.0;
     for (int ci = 0; ci < ctx->chunks_timed; ++ci) {
-        float a = 0.f, b = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev_chunk[3 * ci], ctx->ev_chunk[3 * ci + 1]));
-        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev_chunk[3 * ci + 1], ctx->ev_chunk[3 * ci + 2]));
+        float a = 0.f, b = 0.f, c = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&a, ctx->ev_chunk[4 * ci], ctx->ev_chunk[4 * ci + 1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->ev_chunk[4 * ci + 1], ctx->ev_chunk[4 * ci + 2]));
+        HIP_TRY(ctx, hipEventElapsedTime(&c, ctx->ev_chunk[4 * ci + 2], ctx->ev_chunk[4 * ci + 3]));
         seed += a;
         prop += b;
+        post += c;
     }
+    ctx->last_post_ms = post;
     if (out_seed_ms) *out_seed_ms = seed;
     if (out_propagate_ms) *out_propagate_ms = prop;
     if (out_launches) *out_launches = ctx->chunks_timed ? ctx->chunks_timed : 1;
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_last_estimator_ms(TardisMcContext *ctx, double *out_ms)
+{
+    if (!ctx || !out_ms) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    double seed, prop;
+    int launches;
+    int rc = tardis_mc_last_kernel_times(ctx, &seed, &prop, &launches);
+    if (rc) return rc;
+    *out_ms = ctx->last_post_ms;
     return TARDIS_MC_OK;
 }
 

@@ -110,7 +110,9 @@ class Engine:
         """Device time (ms) of the seeding and propagation launches of the last propagate(), and the launch count."""
         a, b, n = C.c_double(), C.c_double(), C.c_int()
         self._check(self._L.tardis_mc_last_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)), "last_kernel_times")
-        return {"seed_ms": a.value, "propagate_ms": b.value, "launches": n.value}
+        e = C.c_double()
+        self._check(self._L.tardis_mc_last_estimator_ms(self._h, C.byref(e)), "last_estimator_ms")
+        return {"seed_ms": a.value, "propagate_ms": b.value, "launches": n.value, "estimator_ms": e.value}
 
     def get_results(self, output_nus=None, output_energies=None, track_last_interaction=True,
                     want_line_estimators=True, vpacket_log_capacity=None) -> _abi.ResultBuffers:

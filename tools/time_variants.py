@@ -24,5 +24,5 @@ for spec in sys.argv[2:]:
     kt = eng.last_kernel_times()
     cnt = eng.get_results(track_last_interaction=False, want_line_estimators=False).counters
     print('   counters', cnt, flush=True)
-    print(f"{spec:50s} step {best:8.2f} ms  seed {kt['seed_ms']:.2f}  rest {kt['propagate_ms']:.2f}  -> {prob.packet_collection.number_of_packets / best / 1e3:.1f} Mpkt/s", flush=True)
+    print(f"{spec:50s} step {best:8.2f} ms  seed {kt['seed_ms']:.2f}  prop {kt['propagate_ms']:.2f}  est {kt['estimator_ms']:.2f}  -> {prob.packet_collection.number_of_packets / best / 1e3:.1f} Mpkt/s", flush=True)
     eng.close()
