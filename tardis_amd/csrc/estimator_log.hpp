@@ -25,7 +25,9 @@
 namespace mc {
 
 constexpr int EST_TILE = 2048;       // lines per LDS tile (2 x 16 KiB)
-constexpr int EST_SLICE = 4096;      // records per accumulate workgroup
+constexpr int EST_SLICE = 8192;      // records per accumulate workgroup pass
+constexpr int EST_APRON = 256;       // lines past the end of a tile that are still accumulated in LDS (traces start in
+                                     // their bin's tile and may run on into the next one)
 constexpr int EST_MAX_BINS = 16384;  // largest LDS histogram of the binning kernels (dynamic LDS, 4 B per bin = 64 KiB)
 
 struct __attribute__((aligned(16))) LineVisitRecord {
@@ -129,12 +131,12 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(const unsigned *__rest
     }
 }
 
-// Workgroups loop over slices (<= EST_SLICE records of one bin): the bin's tile of both estimators lives in LDS.  A wave
-// stages 64 records at a time (the next 64 are already in flight) and spreads their line visits evenly over its lanes:
-// lane l of pass i handles visit 64 i + l of the batch; the record a visit belongs to is found with one popcount on a
-// bit mask of the record starts.  Records longer than EST_LONG lines are walked by the whole wave one after the other.
-constexpr int EST_LONG = 255;
-constexpr unsigned EST_EMPTY_N = 0u;
+// Workgroups (8 waves) loop over slices (<= EST_SLICE records of one bin): the bin's tile of both estimators lives in
+// LDS.  A wave stages 64 records at a time (the next 128 are already in flight) and spreads their line visits evenly
+// over its lanes: lane l of pass i handles visit 64 i + l of the batch; the record a visit belongs to is found with one
+// popcount on a bit mask of the record starts.  Records longer than EST_LONG lines are walked by the whole wave.
+constexpr int EST_LONG = 63;
+constexpr int ACC_WAVES = 8;
 
 template <bool FULL, bool FAST>
 __device__ __forceinline__ void accumulate_term(double energy, double nu, double rcp_nu, double comov_nu, double mur, double nu_l,
@@ -151,17 +153,20 @@ __device__ __forceinline__ void accumulate_term(double energy, double nu, double
 }
 
 template <bool FULL>
-__global__ void __launch_bounds__(256) accumulate_kernel(const LineVisitRecord *__restrict__ records, const unsigned *__restrict__ sorted_index,
-                                                         const unsigned *__restrict__ bin_start, const unsigned *__restrict__ slice_start,
-                                                         int n_bins, int tiles_per_shell, int n_lines, const double *__restrict__ nu_line,
-                                                         double t_exp, double tc, double rcp_tc, double *__restrict__ jblue_t,
-                                                         double *__restrict__ edot_t)
+__global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVisitRecord *__restrict__ records,
+                                                                    const unsigned *__restrict__ sorted_index,
+                                                                    const unsigned *__restrict__ bin_start,
+                                                                    const unsigned *__restrict__ slice_start, int n_bins,
+                                                                    int tiles_per_shell, int n_lines, const double *__restrict__ nu_line,
+                                                                    double t_exp, double tc, double rcp_tc, double *__restrict__ jblue_t,
+                                                                    double *__restrict__ edot_t)
 {
-    __shared__ double tile_jb[EST_TILE], tile_ed[EST_TILE];
+    constexpr int TILE_LDS = EST_TILE + EST_APRON;
+    __shared__ double tile_jb[TILE_LDS], tile_ed[TILE_LDS];
     // staged records, array of structures: a lane fetches "its" record with three 16-byte LDS reads
     struct __attribute__((aligned(16))) Staged { double energy, nu, rcp_nu, comov_nu, mur; unsigned idx0, first_fast; };
-    __shared__ Staged staged[4][64];
-    __shared__ unsigned long long starts[4][EST_LONG + 1];
+    __shared__ Staged staged[ACC_WAVES][64];
+    __shared__ unsigned long long starts[ACC_WAVES][64];
     const unsigned n_slices = slice_start[n_bins];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long le_mask = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
@@ -178,32 +183,33 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const LineVisitRecord *
         const int shell = bin / tiles_per_shell, tile = bin - shell * tiles_per_shell;
         const unsigned row = (unsigned)shell * (unsigned)n_lines;
         const unsigned tile_idx0 = row + (unsigned)tile * EST_TILE;
-        for (int k = threadIdx.x; k < EST_TILE; k += 256) { tile_jb[k] = 0.0; tile_ed[k] = 0.0; }
+        const unsigned tile_len = min((unsigned)TILE_LDS, (unsigned)n_lines - (unsigned)tile * EST_TILE);  // never past the shell's row
+        for (int k = threadIdx.x; k < TILE_LDS; k += 64 * ACC_WAVES) { tile_jb[k] = 0.0; tile_ed[k] = 0.0; }
         __syncthreads();
 
         auto add_term = [&](unsigned idx, double jb_term, double e_term) {
             const unsigned off = idx - tile_idx0;
-            if (off < (unsigned)EST_TILE) {
+            if (off < tile_len) {
                 atomicAdd(&tile_jb[off], jb_term);
                 atomicAdd(&tile_ed[off], e_term);
-            } else {  // the trace ran past the end of its first tile
+            } else {  // the trace ran far past the end of its first tile
                 atomic_add_f64(&jblue_t[idx], jb_term);
                 atomic_add_f64(&edot_t[idx], e_term);
             }
         };
-        LineVisitRecord next;
-        next.n_flags = 0;
-        {
-            const unsigned r = rec_first + (unsigned)w * 64 + (unsigned)lane;
-            if (r < rec_last) next = records[sorted_index[r]];
-        }
-        for (unsigned base = rec_first + (unsigned)w * 64; base < rec_last; base += 256) {
+        auto fetch = [&](unsigned r) {
+            LineVisitRecord rec;
+            rec.n_flags = 0;
+            if (r < rec_last) rec = records[sorted_index[r]];
+            return rec;
+        };
+        const unsigned stride = 64 * ACC_WAVES;
+        unsigned base = rec_first + (unsigned)w * 64;
+        LineVisitRecord next = fetch(base + (unsigned)lane), next2 = fetch(base + stride + (unsigned)lane);
+        for (; base < rec_last; base += stride) {
             const LineVisitRecord rec = next;
-            next.n_flags = 0;
-            {
-                const unsigned r = base + 256 + (unsigned)lane;
-                if (r < rec_last) next = records[sorted_index[r]];
-            }
+            next = next2;
+            next2 = fetch(base + 2 * stride + (unsigned)lane);
             const unsigned n_all = rec.n_flags & 0x7fffffffu;
             const bool fast = (rec.n_flags >> 31) != 0;
             const unsigned n = n_all > (unsigned)EST_LONG ? 0u : n_all;  // long records are handled below
@@ -216,8 +222,8 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const LineVisitRecord *
             }
             const unsigned excl = incl - n;
             const unsigned total = (unsigned)__shfl((int)incl, 63);
-            const unsigned n_pass = (total + 63) >> 6;
-            for (unsigned k = lane; k < n_pass; k += 64) starts[w][k] = 0ull;
+            const unsigned n_pass = (total + 63) >> 6;  // <= EST_LONG
+            starts[w][lane] = 0ull;
             const double rcp_nu = 1.0 / rec.nu;
             if (n) {  // staged in compacted order: the q-th record that starts is the q-th staged one
                 const int pos = __popcll(__ballot(true) & ((1ull << lane) - 1ull));
@@ -265,8 +271,7 @@ __global__ void __launch_bounds__(256) accumulate_kernel(const LineVisitRecord *
             }
         }
         __syncthreads();
-        const unsigned tile_len = min((unsigned)EST_TILE, (unsigned)n_lines - (unsigned)tile * EST_TILE);
-        for (unsigned k = threadIdx.x; k < tile_len; k += 256) {
+        for (unsigned k = threadIdx.x; k < tile_len; k += 64 * ACC_WAVES) {
             if (tile_jb[k] != 0.0) atomic_add_f64(&jblue_t[tile_idx0 + k], tile_jb[k]);
             if (tile_ed[k] != 0.0) atomic_add_f64(&edot_t[tile_idx0 + k], tile_ed[k]);
         }

@@ -962,7 +962,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     } else {
         // variant 1: cooperative kernel; MT19937 states are seeded per chunk by a lane-per-packet kernel
         long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
-        const bool wave_kernel = ctx->variant == 2 && !vpk;  // wave-owner kernel (lane-per-packet event code, groups as sweep workers)
+        // wave-owner kernel (lane-per-packet event code, groups as sweep workers).  Its macro-atom walk is lane-per-packet,
+        // which is fine for scatter / downbranch (one short block) but not for the long jump chains of macroatom mode
+        // (random 8-byte loads instead of coalesced block reads): those, and v-packets, stay on the group kernel.
+        const bool wave_kernel = ctx->variant == 2 && !vpk && c.line_interaction_type != TARDIS_MC_LINE_MACROATOM;
         if (wave_kernel && ctx->pipeline_chunks > 1 && ctx->n_packets >= (2LL << 20)) {
             // pipeline: ~pipeline_chunks chunks of at least 1 Mi packets, alternating between two streams
             const long long want = (ctx->n_packets + ctx->pipeline_chunks - 1) / ctx->pipeline_chunks;
@@ -1111,13 +1114,13 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                     hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_start, bin_fill, slice_start);
                     hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.cursor, lg.capacity, n_bins,
                                        bin_fill, sorted);
-                    const unsigned acc_blocks = (unsigned)(cus * 5);
+                    const unsigned acc_blocks = (unsigned)(cus * 2);
                     if (full)
-                        hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(256), 0, st, lg.records, sorted, bin_start,
+                        hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
                                            slice_start, n_bins - 1, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
                                            P.jblue_t, P.edot_t);
                     else
-                        hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(256), 0, st, lg.records, sorted, bin_start,
+                        hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
                                            slice_start, n_bins - 1, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
                                            P.jblue_t, P.edot_t);
                 }
