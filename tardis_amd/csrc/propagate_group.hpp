@@ -25,7 +25,7 @@ constexpr int PACKET_BATCH = 16;  // packets reserved per global atomic
 // ---- seeding kernel: raw init_genrand state, [packet][624] contiguous, one packet per lane.
 // Stores go through an LDS tile so that a 16-lane group writes 64 contiguous bytes of one packet's state.
 __global__ void __launch_bounds__(256) seed_states_kernel(const uint32_t *__restrict__ seeds, uint32_t *__restrict__ states,
-                                                          long long first, long long count)
+                                                          long long first, long long count, int stride)
 {
     __shared__ uint32_t tile[256][17];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) seed_states_kernel(const uint32_t *__rest
             int pk = (threadIdx.x >> 4) + 16 * r;
             long long gi = block_first + pk;
             if (gi < count && base + (threadIdx.x & 15) < MT_N)
-                states[(size_t)gi * MT_N + base + (threadIdx.x & 15)] = tile[pk][threadIdx.x & 15];
+                states[(size_t)gi * stride + base + (threadIdx.x & 15)] = tile[pk][threadIdx.x & 15];
         }
         __syncthreads();
     }

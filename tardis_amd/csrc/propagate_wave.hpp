@@ -28,6 +28,8 @@
 
 namespace mc {
 
+constexpr int WV_STATE_STRIDE = 640;  // words between the MT19937 states of two packets: 2560 B, so that no two packets share a
+                                      // 128-byte cache line (a wave never touches memory a seeder may still be writing)
 constexpr int WV_RING = 8;  // look-ahead doubles per packet (power of two; a refill adds 4, so it needs r_cnt <= 4).  16 with 8-double
                             // refills was measured: fewer refill rounds, but the extra 4 KiB of LDS costs the 12th wave of the CU
 enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3 };
@@ -71,6 +73,11 @@ struct WaveCold {
     EstimatorLog log;
     uint32_t *seeded_states;
     long long chunk_first, chunk_count;
+    // in-kernel seeding: the first n_seeders workgroups of the grid produce the MT19937 start states, 64 packets at a time,
+    // and raise seed_flags[tile]; the propagating waves wait for the flag of a packet's tile before they touch its state
+    const uint32_t *seeds;
+    unsigned *seed_flags;
+    int n_seeders;
 };
 
 // One worker slot of a group: the trace it is sweeping (group-uniform values) and this lane's line of the current chunk.
@@ -155,6 +162,44 @@ __device__ __forceinline__ void sweep_step(const WaveHot &P, SweepSlot &s, const
     }
 }
 
+// Seeder role: init_genrand (numpy legacy seeding, mt19937.c) for 64 packets per pass, one packet per lane; the serial
+// recurrence leaves no parallelism inside a packet.  Words go through an LDS tile so that 16 lanes write 64 contiguous
+// bytes of one packet's state.  Seeder waves never wait for anybody, so the waves waiting on seed_flags always get served.
+__device__ __forceinline__ void seed_role(const WaveCold *__restrict__ W, const int lane, unsigned char *lds_raw)
+{
+    uint32_t (*tile)[17] = reinterpret_cast<uint32_t (*)[17]>(lds_raw);  // 64 x 17 words
+    const long long n = W->chunk_count;
+    const long long n_tiles = (n + 63) / 64;
+    const uint32_t *__restrict__ seeds = W->seeds + W->chunk_first;
+    for (long long tl = blockIdx.x; tl < n_tiles; tl += W->n_seeders) {
+        const long long i = tl * 64 + lane;
+        uint32_t x = i < n ? seeds[i] : 0u;
+        uint32_t *__restrict__ out = W->seeded_states + (size_t)tl * 64 * WV_STATE_STRIDE;
+        const int n_valid = (int)min(64LL, n - tl * 64);
+        for (int base = 0; base < MT_N; base += 16) {
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const int k = base + w;
+                if (k > 0) x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
+                tile[lane][w] = x;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pk = (lane >> 4) + 4 * r;
+                // agent-scope (write-through) stores: the states must be visible to the other XCDs without an L2 write-back
+                if (pk < n_valid)
+                    __hip_atomic_store(&out[(size_t)pk * WV_STATE_STRIDE + base + (lane & 15)], tile[pk][lane & 15], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every state word has been written through
+        if (lane == 0) __hip_atomic_store(&W->seed_flags[tl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <bool FULL, bool TRACK, int G>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
@@ -164,6 +209,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     double *lds_J = reinterpret_cast<double *>(lds_raw + sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0));
     double *lds_nubar = lds_J + H.n_shells;
     const int lane = threadIdx.x;  // one wave per workgroup
+    if ((int)blockIdx.x < W->n_seeders) {
+        seed_role(W, lane, lds_raw);
+        return;
+    }
     for (int s = lane; s < 2 * H.n_shells; s += 64) lds_J[s] = 0.0;
 
     const int j = lane & (G - 1);
@@ -219,7 +268,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             const int src = my_owner >= 0 ? my_owner : lane;
             const int o_pkt = __shfl(pkt, src), o_gpos = __shfl(r_gpos, src), o_tail = __shfl((r_head + r_cnt) & (WV_RING - 1), src);
             if (my_owner >= 0) {
-                uint32_t *st = seeded_states + (size_t)((H.debug_flags & 64) ? (o_pkt & 1023) : o_pkt) * MT_N;
+                uint32_t *st = seeded_states + (size_t)o_pkt * WV_STATE_STRIDE;
                 const int k = o_gpos + sj;
                 const int k1 = (k + 1 == MT_N) ? 0 : k + 1;
                 const int km = (k + 397 >= MT_N) ? k + 397 - MT_N : k + 397;
@@ -441,6 +490,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     else {
                         pkt = (int)mine;
                         r_gpos = r_head = r_cnt = 0;
+                        if (W->n_seeders > 0) {  // the start state of this packet comes from a seeder wave of this launch
+                            unsigned spins = 0;
+                            // (relaxed polling: nobody on this CU / XCD has touched the packet's cache lines before, so there is nothing
+                            // stale to invalidate, and an acquire per fetch would flush the L1 under the sweeps)
+                            while (__hip_atomic_load(&W->seed_flags[mine >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                                __builtin_amdgcn_s_sleep(8);
+                                if (++spins > (1u << 22)) { atomicMin(&P.cold->first_error[0], chunk_first + mine); break; }
+                            }
+                        }
                         const long long i = chunk_first + mine;
                         const DeviceProblem *C = P.cold;
                         p.r = C->r0[i]; p.mu = C->mu0[i]; p.nu = C->nu0[i]; p.energy = C->e0[i];
@@ -500,7 +558,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 sh.d_cont0[lane] = tau_event / chi_e;  // distance_continuum in force at the first line
                 if (FULL) { shf.r[lane] = p.r; shf.mu[lane] = p.mu; }
                 sh.cursor[lane] = p.next_line_id;
-                sh.rowfast[lane] = (int)((((P.debug_flags & 32) ? 0u : (unsigned)p.shell) * (unsigned)L) | (fast ? 0x80000000u : 0u));
+                sh.rowfast[lane] = (int)(((unsigned)p.shell * (unsigned)L) | (fast ? 0x80000000u : 0u));
                 state = WS_SWEEP;
             }
             const unsigned long long go_mask = __ballot(go);

@@ -131,7 +131,10 @@ struct TardisMcContext {
     // chunk overlap the propagation of its neighbours
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], seeded_states2, next_packet2, wave_cold_dev;
+    DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], seeded_states2, next_packet2, wave_cold_dev, seed_flags[2];
+    int seed_in_kernel = 0;  // >0: the MT19937 start states are produced by this many seeder waves per CU inside the propagation launch.
+                             // Measured: the 25 GB of state writes slow the (latency-bound) sweeps by exactly the time the separate
+                             // seeding kernel takes, so the default stays the separate kernel.
     int pipeline_chunks = 1;  // >1: split a propagate call of the wave kernel into chunks on two streams (measured: a loss -- every chunk pays the drain of its last packets)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
     std::vector<mc::WaveCold> wave_cold_host;
@@ -508,6 +511,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
         ctx->log_sorted[b].release();
     }
     ctx->seeded_states2.release(); ctx->next_packet2.release(); ctx->wave_cold_dev.release();
+    ctx->seed_flags[0].release(); ctx->seed_flags[1].release();
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
@@ -534,6 +538,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
+    else if (n == "seed_in_kernel") ctx->seed_in_kernel = std::max(0, std::min(16, (int)value));
     else if (n == "pipeline_chunks") ctx->pipeline_chunks = std::max(1, (int)value);
     else if (n == "log_capacity") ctx->log_capacity = std::max<long long>(0, value);
     else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
@@ -977,9 +982,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
-        HIP_TRY(ctx, ctx->seeded_states.ensure((size_t)chunk * mc::MT_N * sizeof(uint32_t)));
+        HIP_TRY(ctx, ctx->seeded_states.ensure((size_t)chunk * mc::WV_STATE_STRIDE * sizeof(uint32_t)));
         if (two_streams) {
-            HIP_TRY(ctx, ctx->seeded_states2.ensure((size_t)chunk * mc::MT_N * sizeof(uint32_t)));
+            HIP_TRY(ctx, ctx->seeded_states2.ensure((size_t)chunk * mc::WV_STATE_STRIDE * sizeof(uint32_t)));
             HIP_TRY(ctx, ctx->next_packet2.ensure(sizeof(unsigned long long)));
         }
         ctx->problem_host = make_device_problem(ctx);
@@ -1073,9 +1078,16 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 ctx->ev_chunk.push_back(e);
             }
             HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci], st));
-            hipLaunchKernelGGL(mc::seed_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
-                               ctx->seeds.as<uint32_t>(), seeded, first, count);
-            HIP_TRY(ctx, hipGetLastError());
+            const bool seeders = wave_kernel && ctx->seed_in_kernel;
+            const long long n_tiles = (count + 63) / 64;
+            if (seeders) {
+                HIP_TRY(ctx, ctx->seed_flags[b].ensure((size_t)n_tiles * sizeof(unsigned)));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->seed_flags[b].p, 0, (size_t)n_tiles * sizeof(unsigned), st));
+            } else {
+                hipLaunchKernelGGL(mc::seed_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                                   ctx->seeds.as<uint32_t>(), seeded, first, count, wave_kernel ? mc::WV_STATE_STRIDE : mc::MT_N);
+                HIP_TRY(ctx, hipGetLastError());
+            }
             HIP_TRY(ctx, hipMemsetAsync(next_packet, 0, sizeof(unsigned long long), st));
             HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 1], st));
             const int groups_per_block = block / G;
@@ -1094,13 +1106,16 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 mc::WaveCold &wc = ctx->wave_cold_host[ci];
                 wc.P = P; wc.P.next_packet = next_packet; wc.log = lg; wc.seeded_states = seeded;
                 wc.chunk_first = first; wc.chunk_count = count;
+                wc.seeds = ctx->seeds.as<uint32_t>();
+                wc.seed_flags = seeders ? ctx->seed_flags[b].as<unsigned>() : nullptr;
+                wc.n_seeders = seeders ? (int)std::min<long long>((long long)cus * ctx->seed_in_kernel, n_tiles) : 0;
                 mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci;
                 HIP_TRY(ctx, hipMemcpyAsync(wc_dev, &wc, sizeof(mc::WaveCold), hipMemcpyHostToDevice, st));
                 mc::WaveHot hot{};
                 hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
                 hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
                 hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
-                hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
+                hipLaunchKernelGGL(kw, dim3(waves + wc.n_seeders), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));
                 if (lg.capacity > 0) {
