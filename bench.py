@@ -14,8 +14,9 @@ of the estimator arrays (J, nu_bar, j_blue, Edotlu, v-hist) that an outer plasma
 Workload (N = 1): BASELINE.json configs[1] -- tardis_example shape, 1e7 packets, 20 shells, ~3e4 lines,
 downbranch, no v-packets, synthetic opacities (the reference's atomic data is not available offline).
 
-The JSON line carries `roofline` (algorithmic bytes of the propagation kernel per launch / its HIP-event time,
-against the 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle -- the parity-pinned C port of the reference
+The JSON line carries `roofline` (algorithmic bytes of a step's propagation per launch / the HIP-event time of the
+dominant kernel -- the propagation kernel; the seeding kernel and the line-estimator passes of the step are reported
+beside it -- against the 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle -- the parity-pinned C port of the reference
 algorithm -- timed on this box's cores on a bounded sample of the same workload).
 """
 from __future__ import annotations
@@ -38,10 +39,17 @@ from tardis_amd.engine import Engine  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes(c: dict) -> float:
-    """48 B per line visit, 56 B per event, 8 B per macro-atom transition examined, 16 B per
-    v-packet line visit, 56 B of per-packet I/O (+112 B of last-interaction output when tracking)."""
-    return (48.0 * c["line_visits"] + 56.0 * c["events"] + 8.0 * c["macro_transitions"] + 16.0 * c["vpacket_line_visits"]
+def algorithmic_bytes(c: dict, part: str = "step") -> float:
+    """48 B per line visit (nu_line 8 + tau 8 + the read-modify-writes of j_blue and Edotlu, 16 each), 56 B
+    per event, 8 B per macro-atom transition examined, 16 B per v-packet line visit, 56 B of per-packet I/O.
+
+    part = "step": everything a Monte Carlo iteration moves.  With the wave kernel the line-estimator read-modify-writes
+    are not done by the propagation kernel (it logs one record per trace, the accumulate kernel applies them), so the
+    dominant kernel's own share is part = "propagate": 16 B per line visit + the rest; part = "estimators": 32 B per visit."""
+    per_visit = {"step": 48.0, "propagate": 16.0, "estimators": 32.0}[part]
+    if part == "estimators":
+        return per_visit * c["line_visits"]
+    return (per_visit * c["line_visits"] + 56.0 * c["events"] + 8.0 * c["macro_transitions"] + 16.0 * c["vpacket_line_visits"]
             + 56.0 * c["packets"])
 
 
@@ -141,13 +149,18 @@ def main():
     if pg.rank == 0:
         # dominant kernel = the propagation kernel; its launches of one step are timed with HIP events on the engine stream
         launches = max(ktimes["launches"], 1)
+        wave = (args.variant in (None, 2)) and kw.get("n_vpackets", 0) == 0 and kw["line_interaction_type"] != "macroatom"
+        dominant = "propagate_wave_kernel" if wave else ("propagate_lane_kernel" if args.variant == 0 else "propagate_group_kernel")
         kernel_ms = ktimes["propagate_ms"] / launches
-        bytes_per_launch = algorithmic_bytes(counters) / launches
+        # the dominant kernel's own algorithmic bytes (see algorithmic_bytes) over its HIP-event duration
+        bytes_per_launch = algorithmic_bytes(counters, "propagate" if wave else "step") / launches
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        step_bytes = algorithmic_bytes(counters, "step")
+        step_achieved = step_bytes / (last_ms * 1e-3) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         default_workload = (args.config == 2 and args.packets is None and args.lines is None and args.shells is None
-                            and args.mode is None and args.vpackets is None and not args.no_tracking)
+                            and args.mode is None and args.vpackets is None and not args.no_tracking and args.variant is None)
         if default_workload and os.path.exists(pmc_path):  # the PMC passes were collected on the default workload
             try:
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
@@ -155,9 +168,12 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": "propagate_group_kernel (dominant kernel of a step)", "kernel_ms": kernel_ms,
-                           "launches_per_step": launches, "seed_kernel_ms_per_step": ktimes["seed_ms"], "step_device_ms": last_ms,
-                           "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "kernel": f"{dominant} (dominant kernel of a step)", "kernel_ms": kernel_ms,
+                           "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "step": {"algorithmic_bytes": step_bytes, "device_ms": last_ms, "achieved": step_achieved,
+                                    "frac": step_achieved / HBM_PEAK_GBS, "seed_kernel_ms": ktimes["seed_ms"],
+                                    "estimator_passes_ms": ktimes.get("estimator_ms", 0.0),
+                                    "note": "all kernels of one iteration: MT19937 seeding, propagation, line-estimator passes"},
                            "per_packet": {k: counters[k] / max(P, 1) for k in ("line_visits", "events", "macro_transitions", "rng_draws")}}
         if n_gpus == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(prob, eng, min(args.cpu_sample, P))

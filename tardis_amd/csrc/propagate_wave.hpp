@@ -273,10 +273,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 const int k1 = (k + 1 == MT_N) ? 0 : k + 1;
                 const int km = (k + 397 >= MT_N) ? k + 397 - MT_N : k + 397;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t a = st[k], b = st[k1], c = st[km];
+                const uint32_t a = __builtin_nontemporal_load(&st[k]), b = __builtin_nontemporal_load(&st[k1]), c = __builtin_nontemporal_load(&st[km]);
                 const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
                 const uint32_t v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                st[k] = v;
+                __builtin_nontemporal_store(v, &st[k]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 const uint32_t nb = (uint32_t)__shfl_down((int)v, 1, 8);
                 if (!(sj & 1)) sh.ring[(o_tail + (sj >> 1)) & (WV_RING - 1)][my_owner] = GroupRng<8>::to_double(v, nb);
@@ -331,8 +331,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     rec.n_flags = (unsigned)n_visit | ((unsigned)(pflags & 1) << 31);
                     rec.pad[0] = rec.pad[1] = 0;
                     if (slot < log.capacity) {
-                        log.records[slot] = rec;
-                        log.keys[slot] = (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE);
+                        // streaming stores: the log must not push the opacity table out of the L2
+                        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                        const v4u *src = reinterpret_cast<const v4u *>(&rec);
+                        v4u *dst = reinterpret_cast<v4u *>(&log.records[slot]);
+                        __builtin_nontemporal_store(src[0], dst);
+                        __builtin_nontemporal_store(src[1], dst + 1);
+                        __builtin_nontemporal_store(src[2], dst + 2);
+                        __builtin_nontemporal_store((unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE), &log.keys[slot]);
                     } else {  // log full: add the terms directly (slow, only when the host under-sized the log)
                         const bool fast = (pflags & 1) != 0;
                         const double rcp_nu = 1.0 / rec.nu;
@@ -343,7 +349,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             atomic_add_f64(&ed[rec.idx0 + (unsigned)k], e_term);
                         }
                     }
-                } else if (slot < log.capacity) log.keys[slot] = (unsigned)log.empty_bin;
+                } else if (slot < log.capacity) __builtin_nontemporal_store((unsigned)log.empty_bin, &log.keys[slot]);
             }
         }
         // ---- epilogue of the finished traces: move, estimators, boundary / scattering

@@ -50,7 +50,7 @@ def traffic_json(root, out_path):
         with open(out_path, "w") as f:
             json.dump({"hbm_bytes_per_launch": hbm, "FETCH_SIZE_KiB_per_launch": vals["FETCH_SIZE"],
                        "WRITE_SIZE_KiB_per_launch": vals["WRITE_SIZE"],
-                       "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024; propagate_group_kernel, default bench workload"}, f)
+                       "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024; propagation kernel (propagate_wave_kernel / propagate_group_kernel), default bench workload"}, f)
 
 
 def main():
