@@ -30,23 +30,6 @@ constexpr int EST_APRON = 256;       // lines past the end of a tile that are st
                                      // their bin's tile and may run on into the next one)
 constexpr int EST_MAX_BINS = 16384;  // largest LDS histogram of the binning kernels (dynamic LDS, 4 B per bin = 64 KiB)
 
-struct __attribute__((aligned(16))) LineVisitRecord {
-    double energy, nu, comov_nu, mur;  // packet state at the start of the trace (mur = mu * r)
-    unsigned idx0;                     // shell * n_lines + first line visited
-    unsigned n_flags;                  // number of lines visited | (exact-division fast path << 31)
-    unsigned pad[2];
-};
-static_assert(sizeof(LineVisitRecord) == 48, "record layout");
-
-struct EstimatorLog {
-    LineVisitRecord *records;
-    unsigned *keys;                    // bin of each record
-    unsigned long long *cursor;        // next free record
-    unsigned long long capacity;
-    int tiles_per_shell;
-    int empty_bin;                     // key of a reserved but unused slot (= number of real bins)
-};
-
 // the term update_line_estimators adds for line `nu_line` (estimators_line.py; the sweep's pend_e / pend_jb)
 template <bool FULL>
 __device__ __forceinline__ void line_estimator_terms(const LineVisitRecord &rec, bool fast, double rcp_nu, double nu_line, double t_exp,
@@ -64,15 +47,17 @@ __device__ __forceinline__ void line_estimator_terms(const LineVisitRecord &rec,
     jb_term = fast ? exact_div<true>(e_term, rec.nu, rcp_nu) : e_term / rec.nu;
 }
 
-__global__ void __launch_bounds__(256) bin_count_kernel(const unsigned *__restrict__ keys, const unsigned long long *__restrict__ cursor,
-                                                        unsigned long long capacity, int n_bins, unsigned *__restrict__ bin_count)
+__global__ void __launch_bounds__(256) bin_count_kernel(const unsigned *__restrict__ keys, const unsigned *__restrict__ region_count,
+                                                        int n_regions, unsigned region_capacity, int n_bins, unsigned *__restrict__ bin_count)
 {
     extern __shared__ unsigned hist[];
-    const unsigned long long n = min(*cursor, capacity);
     for (int b = threadIdx.x; b < n_bins; b += 256) hist[b] = 0;
     __syncthreads();
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256)
-        atomicAdd(&hist[keys[i]], 1u);
+    for (int r = blockIdx.x; r < n_regions; r += gridDim.x) {
+        const unsigned n = min(region_count[r], region_capacity);
+        const unsigned *__restrict__ k = keys + (size_t)r * region_capacity;
+        for (unsigned i = threadIdx.x; i < n; i += 256) atomicAdd(&hist[k[i]], 1u);
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < n_bins; b += 256)
         if (hist[b]) atomicAdd(&bin_count[b], hist[b]);
@@ -80,11 +65,10 @@ __global__ void __launch_bounds__(256) bin_count_kernel(const unsigned *__restri
 
 // one workgroup: exclusive scan of the bin counts -> bin_start[n_bins + 1]; slices of at most EST_SLICE records ->
 // slice_start[n_bins + 1] (prefix of the per-bin slice counts); bin_fill is reset to the bin starts for the scatter.
-// (bin n_bins - 1 is the "empty slot" bin: it is sorted like the others but gets no slices)
 __global__ void __launch_bounds__(256) bin_scan_kernel(const unsigned *__restrict__ bin_count, int n_bins, unsigned *__restrict__ bin_start,
                                                        unsigned *__restrict__ bin_fill, unsigned *__restrict__ slice_start)
 {
-    auto slices = [&](int b) { return b == n_bins - 1 ? 0u : (bin_count[b] + EST_SLICE - 1) / EST_SLICE; };
+    auto slices = [&](int b) { return (bin_count[b] + EST_SLICE - 1) / EST_SLICE; };
     __shared__ unsigned part_r[256], part_s[256];
     const int per = (n_bins + 255) / 256;
     const int b0 = threadIdx.x * per, b1 = min(n_bins, b0 + per);
@@ -105,29 +89,33 @@ __global__ void __launch_bounds__(256) bin_scan_kernel(const unsigned *__restric
     if (b1 == n_bins && b0 <= n_bins) { bin_start[n_bins] = r; slice_start[n_bins] = s; }
 }
 
-// counting-sort scatter of the record indices: every workgroup takes a contiguous slice of the log, ranks its records
-// per bin in LDS, reserves the output ranges with one global atomic per non-empty bin and writes the indices.
-__global__ void __launch_bounds__(256) bin_scatter_kernel(const unsigned *__restrict__ keys, const unsigned long long *__restrict__ cursor,
-                                                          unsigned long long capacity, int n_bins, unsigned *__restrict__ bin_fill,
-                                                          unsigned *__restrict__ sorted_index)
+// counting-sort scatter of the record indices: every workgroup takes a set of log regions, ranks their records per bin
+// in LDS, reserves the output ranges with one global atomic per non-empty bin and writes the (global) record indices.
+__global__ void __launch_bounds__(256) bin_scatter_kernel(const unsigned *__restrict__ keys, const unsigned *__restrict__ region_count,
+                                                          int n_regions, unsigned region_capacity, int n_bins,
+                                                          unsigned *__restrict__ bin_fill, unsigned *__restrict__ sorted_index)
 {
     extern __shared__ unsigned hist[];
-    const unsigned long long n = min(*cursor, capacity);
-    const unsigned long long per_block = (n + gridDim.x - 1) / gridDim.x;
-    const unsigned long long first = (unsigned long long)blockIdx.x * per_block;
-    const unsigned long long last = min(n, first + per_block);
     for (int b = threadIdx.x; b < n_bins; b += 256) hist[b] = 0;
     __syncthreads();
-    for (unsigned long long i = first + threadIdx.x; i < last; i += 256) atomicAdd(&hist[keys[i]], 1u);
+    for (int r = blockIdx.x; r < n_regions; r += gridDim.x) {
+        const unsigned n = min(region_count[r], region_capacity);
+        const unsigned *__restrict__ k = keys + (size_t)r * region_capacity;
+        for (unsigned i = threadIdx.x; i < n; i += 256) atomicAdd(&hist[k[i]], 1u);
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < n_bins; b += 256) {
         const unsigned c = hist[b];
         hist[b] = c ? atomicAdd(&bin_fill[b], c) : 0u;  // base of this block's range in bin b
     }
     __syncthreads();
-    for (unsigned long long i = first + threadIdx.x; i < last; i += 256) {
-        const unsigned pos = atomicAdd(&hist[keys[i]], 1u);
-        sorted_index[pos] = (unsigned)i;
+    for (int r = blockIdx.x; r < n_regions; r += gridDim.x) {
+        const unsigned n = min(region_count[r], region_capacity);
+        const size_t base = (size_t)r * region_capacity;
+        for (unsigned i = threadIdx.x; i < n; i += 256) {
+            const unsigned pos = atomicAdd(&hist[keys[base + i]], 1u);
+            sorted_index[pos] = (unsigned)(base + i);
+        }
     }
 }
 

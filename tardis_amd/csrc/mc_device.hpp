@@ -20,6 +20,24 @@ enum : int { ERR_MONTECARLO = -3, ERR_MACRO_ATOM = -4, ERR_UNSUPPORTED = -5 };
 
 constexpr int MT_N = 624;
 
+// ---- deferred line-estimator accumulation (estimator_log.hpp): one record per trace
+struct __attribute__((aligned(16))) LineVisitRecord {
+    double energy, nu, comov_nu, mur;  // packet state at the start of the trace (mur = mu * r)
+    unsigned idx0;                     // shell * n_lines + first line visited
+    unsigned n_flags;                  // number of lines visited | (exact-division fast path << 31)
+    unsigned pad[2];
+};
+static_assert(sizeof(LineVisitRecord) == 48, "record layout");
+
+struct EstimatorLog {
+    LineVisitRecord *records;          // [n_regions][region_capacity]: every wave appends to its own region (no atomics)
+    unsigned *keys;                    // bin of each record, same layout
+    unsigned *region_count;            // [n_regions] records written by each wave (stored when the wave exits)
+    unsigned region_capacity;          // 0: no log, the kernels add their terms directly
+    int n_regions;
+    int tiles_per_shell;
+};
+
 // Everything a propagation kernel needs, passed by value (kernarg segment -> SGPRs).
 struct DeviceProblem {
     // packets (SoA, coalesced by packet index)
@@ -71,6 +89,7 @@ struct DeviceProblem {
     long long *first_error;         // {packet index (min), code}
     unsigned long long *next_packet;  // work counter for persistent scheduling
     int debug_flags;                  // profiling experiments only: 1 = skip j_blue/Edotlu atomics, 2 = skip J/nu_bar
+    EstimatorLog log;                 // line-visit log of the cooperative kernels (capacity 0: they add their terms directly)
 };
 
 // Slim by-value argument block of the cooperative kernel: only what the inner loops touch stays in SGPRs; everything

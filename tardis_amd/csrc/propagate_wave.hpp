@@ -236,8 +236,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     bool trk_any = false;
     bool exhausted = false;  // wave-uniform: the chunk has no more packets
     int q_head = 0, q_tail = 0;  // wave-uniform: queue of prepared traces
-    unsigned long long log_next = 0;  // lane 0: first of the 64 log slots reserved for the next pass
-    if (lane == 0) log_next = atomicAdd(W->log.cursor, 64ull);
+    unsigned log_used = 0;  // wave-uniform: records this wave has appended to its log region
     unsigned long long visits = 0;
     unsigned dbg_rounds = 0;  // wave-uniform profiling counter: sweep rounds (reported through counters[7])
 
@@ -317,29 +316,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 type = code == 1 ? IT_BOUNDARY : (code == 2 ? IT_ESCATTERING : IT_LINE);
                 if (P.debug_flags & 1) n_visit = 0;
             }
-            // the 64 log slots of this pass were reserved during the previous one (the returning atomic's latency is
-            // hidden behind a whole sweep phase); lanes without a record mark their slot as empty
-            if (__ballot(ready)) {
-                const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)log_next);
-                const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(log_next >> 32));
-                const unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)lane;
-                if (lane == 0) log_next = atomicAdd(log.cursor, 64ull);
+            // every wave appends to its own region of the log: no atomics, no empty slots
+            const unsigned long long have = __ballot(n_visit > 0);
+            if (have) {
+                const unsigned my = log_used + (unsigned)__popcll(have & ((1ull << lane) - 1ull));
+                log_used += (unsigned)__popcll(have);
                 if (n_visit > 0) {
                     LineVisitRecord rec;
                     rec.energy = p.energy; rec.nu = p.nu; rec.comov_nu = p.nu * dop; rec.mur = p.mu * p.r;
                     rec.idx0 = (unsigned)p.shell * (unsigned)L + (unsigned)start;
                     rec.n_flags = (unsigned)n_visit | ((unsigned)(pflags & 1) << 31);
                     rec.pad[0] = rec.pad[1] = 0;
-                    if (slot < log.capacity) {
-                        // streaming stores: the log must not push the opacity table out of the L2
-                        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                        const v4u *src = reinterpret_cast<const v4u *>(&rec);
-                        v4u *dst = reinterpret_cast<v4u *>(&log.records[slot]);
-                        __builtin_nontemporal_store(src[0], dst);
-                        __builtin_nontemporal_store(src[1], dst + 1);
-                        __builtin_nontemporal_store(src[2], dst + 2);
-                        __builtin_nontemporal_store((unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE), &log.keys[slot]);
-                    } else {  // log full: add the terms directly (slow, only when the host under-sized the log)
+                    if (my < log.region_capacity) {
+                        const size_t slot = (size_t)blockIdx.x * log.region_capacity + my;
+                        log.records[slot] = rec;
+                        log.keys[slot] = (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE);
+                    } else {  // region full (or no log): add the terms directly (slow path)
                         const bool fast = (pflags & 1) != 0;
                         const double rcp_nu = 1.0 / rec.nu;
                         for (int k = 0; k < n_visit; ++k) {
@@ -349,7 +341,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             atomic_add_f64(&ed[rec.idx0 + (unsigned)k], e_term);
                         }
                     }
-                } else if (slot < log.capacity) __builtin_nontemporal_store((unsigned)log.empty_bin, &log.keys[slot]);
+                }
             }
         }
         // ---- epilogue of the finished traces: move, estimators, boundary / scattering
@@ -629,12 +621,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         }
     }
 
-    {   // the slots reserved for a pass that never came
-        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)log_next);
-        const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(log_next >> 32));
-        const unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + (unsigned long long)lane;
-        if (slot < W->log.capacity) W->log.keys[slot] = (unsigned)W->log.empty_bin;
-    }
+    if (lane == 0 && W->log.region_capacity > 0) W->log.region_count[blockIdx.x] = min(log_used, W->log.region_capacity);
     const DeviceProblem *C = W->P.cold;
     for (int s = lane; s < H.n_shells; s += 64) {
         if (lds_J[s] != 0.0) atomic_add_f64(&C->J[s], lds_J[s]);

@@ -1035,25 +1035,60 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         // estimator log of the wave kernel (estimator_log.hpp)
         mc::EstimatorLog elog{};
         int n_bins = 0;
+        unsigned long long log_cap = 0;
         if (wave_kernel) {
             const int tiles = (ctx->n_lines + mc::EST_TILE - 1) / mc::EST_TILE;
             n_bins = ctx->n_shells * std::max(tiles, 1);
             // the log must hold the traces of one chunk: ~64 per packet unless the caller says otherwise
             unsigned long long cap = std::min<unsigned long long>((unsigned long long)ctx->log_capacity, (unsigned long long)chunk * 96ull + 65536ull);
-            if (n_bins + 1 > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernel adds its terms directly
+            if (n_bins > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernels add their terms directly
             cap = std::min<unsigned long long>(cap, 0xfffffff0ull);
             for (int b = 0; b < (two_streams ? 2 : 1); ++b) {
                 HIP_TRY(ctx, ctx->log_records[b].ensure(std::max<size_t>(cap, 1) * sizeof(mc::LineVisitRecord)));
                 HIP_TRY(ctx, ctx->log_keys[b].ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
                 HIP_TRY(ctx, ctx->log_sorted[b].ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
-                HIP_TRY(ctx, ctx->log_cursor[b].ensure(sizeof(unsigned long long)));
                 HIP_TRY(ctx, ctx->log_bins[b].ensure((size_t)(4 * (n_bins + 2)) * sizeof(unsigned)));
             }
-            elog.capacity = cap;
             elog.tiles_per_shell = std::max(tiles, 1);
-            elog.empty_bin = n_bins;
-            n_bins += 1;  // + the bin of reserved but unused log slots
+            log_cap = cap;
         }
+        // (the log is split into one region per wave of a launch: set_log_regions fills in the rest)
+        auto set_log_regions = [&](mc::EstimatorLog &lg, int b, int n_regions, hipStream_t st) -> hipError_t {
+            lg.records = ctx->log_records[b].as<mc::LineVisitRecord>();
+            lg.keys = ctx->log_keys[b].as<unsigned>();
+            lg.n_regions = n_regions;
+            lg.region_capacity = (unsigned)std::min<unsigned long long>(log_cap / (unsigned long long)std::max(n_regions, 1), 0x7fffffffull);
+            hipError_t e = ctx->log_cursor[b].ensure((size_t)std::max(n_regions, 1) * sizeof(unsigned));
+            if (e != hipSuccess) return e;
+            lg.region_count = ctx->log_cursor[b].as<unsigned>();
+            return hipMemsetAsync(lg.region_count, 0, (size_t)std::max(n_regions, 1) * sizeof(unsigned), st);
+        };
+        // binning + accumulation of one chunk's line-visit log (estimator_log.hpp)
+        auto estimator_passes = [&](const mc::EstimatorLog &lg, int b, hipStream_t st) -> hipError_t {
+            if (lg.region_capacity == 0) return hipSuccess;
+            unsigned *bin_count = ctx->log_bins[b].as<unsigned>(), *bin_start = bin_count + (n_bins + 1),
+                     *bin_fill = bin_start + (n_bins + 1), *slice_start = bin_fill + (n_bins + 1);
+            unsigned *sorted = ctx->log_sorted[b].as<unsigned>();
+            hipError_t e = hipMemsetAsync(bin_count, 0, (size_t)(n_bins + 1) * sizeof(unsigned), st);
+            if (e != hipSuccess) return e;
+            const size_t hist_lds = (size_t)n_bins * sizeof(unsigned);
+            const int bin_blocks = cus * 4;
+            hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.region_count, lg.n_regions,
+                               lg.region_capacity, n_bins, bin_count);
+            hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_start, bin_fill, slice_start);
+            hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.region_count, lg.n_regions,
+                               lg.region_capacity, n_bins, bin_fill, sorted);
+            const unsigned acc_blocks = (unsigned)(cus * 2);
+            if (full)
+                hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
+                                   slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
+                                   P.jblue_t, P.edot_t);
+            else
+                hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
+                                   slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
+                                   P.jblue_t, P.edot_t);
+            return hipGetLastError();
+        };
         if (wave_kernel) {
             const size_t n_chunks = (size_t)((ctx->n_packets + chunk - 1) / chunk) + 1;
             HIP_TRY(ctx, ctx->wave_cold_dev.ensure(n_chunks * sizeof(mc::WaveCold)));
@@ -1096,11 +1131,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             if (wave_kernel) {
                 const long long want_waves = (count + 63) / 64;
                 const int waves = (int)std::max<long long>(1, std::min<long long>(want_waves, (long long)cus * wave_waves_per_cu));
+                const int n_seed_waves = seeders ? (int)std::min<long long>((long long)cus * ctx->seed_in_kernel, n_tiles) : 0;
                 mc::EstimatorLog lg = elog;
-                lg.records = ctx->log_records[b].as<mc::LineVisitRecord>();
-                lg.keys = ctx->log_keys[b].as<unsigned>();
-                lg.cursor = ctx->log_cursor[b].as<unsigned long long>();
-                HIP_TRY(ctx, hipMemsetAsync(lg.cursor, 0, sizeof(unsigned long long), st));
+                HIP_TRY(ctx, set_log_regions(lg, b, waves + n_seed_waves, st));
                 // cold arguments of this launch: one device slot per chunk (the host copies stay alive in ctx->wave_cold_host)
                 if ((int)ctx->wave_cold_host.size() <= ci) ctx->wave_cold_host.resize(ci + 1);
                 mc::WaveCold &wc = ctx->wave_cold_host[ci];
@@ -1108,7 +1141,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 wc.chunk_first = first; wc.chunk_count = count;
                 wc.seeds = ctx->seeds.as<uint32_t>();
                 wc.seed_flags = seeders ? ctx->seed_flags[b].as<unsigned>() : nullptr;
-                wc.n_seeders = seeders ? (int)std::min<long long>((long long)cus * ctx->seed_in_kernel, n_tiles) : 0;
+                wc.n_seeders = n_seed_waves;
                 mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci;
                 HIP_TRY(ctx, hipMemcpyAsync(wc_dev, &wc, sizeof(mc::WaveCold), hipMemcpyHostToDevice, st));
                 mc::WaveHot hot{};
@@ -1118,28 +1151,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 hipLaunchKernelGGL(kw, dim3(waves + wc.n_seeders), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));
-                if (lg.capacity > 0) {
-                    unsigned *bin_count = ctx->log_bins[b].as<unsigned>(), *bin_start = bin_count + (n_bins + 1),
-                             *bin_fill = bin_start + (n_bins + 1), *slice_start = bin_fill + (n_bins + 1);
-                    unsigned *sorted = ctx->log_sorted[b].as<unsigned>();
-                    HIP_TRY(ctx, hipMemsetAsync(bin_count, 0, (size_t)(n_bins + 1) * sizeof(unsigned), st));
-                    const size_t hist_lds = (size_t)n_bins * sizeof(unsigned);
-                    const int bin_blocks = cus * 4;
-                    hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.cursor, lg.capacity, n_bins, bin_count);
-                    hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_start, bin_fill, slice_start);
-                    hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.cursor, lg.capacity, n_bins,
-                                       bin_fill, sorted);
-                    const unsigned acc_blocks = (unsigned)(cus * 2);
-                    if (full)
-                        hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
-                                           slice_start, n_bins - 1, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
-                                           P.jblue_t, P.edot_t);
-                    else
-                        hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
-                                           slice_start, n_bins - 1, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
-                                           P.jblue_t, P.edot_t);
-                }
+                HIP_TRY(ctx, estimator_passes(lg, b, st));
             } else {
+                // (the group kernel updates the line estimators with atomics: logging its traces was measured and is a loss
+                // there -- the record bookkeeping costs its redundant-lane event loop more than the deferred atomics do)
                 hipLaunchKernelGGL(k, dim3(blocks), dim3(block), lds, st, P, seeded, first, count);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));
