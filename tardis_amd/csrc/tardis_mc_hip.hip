@@ -137,6 +137,7 @@ struct TardisMcContext {
                              // seeding kernel takes, so the default stays the separate kernel.
     int pipeline_chunks = 1;  // >1: split a propagate call of the wave kernel into chunks on two streams (measured: a loss -- every chunk pays the drain of its last packets)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
+    double traces_per_packet = 0.0;  // measured by the last get_results (sizes the line-visit log of the next propagate)
     std::vector<mc::WaveCold> wave_cold_host;
     int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
     // RCCL
@@ -1039,8 +1040,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         if (wave_kernel) {
             const int tiles = (ctx->n_lines + mc::EST_TILE - 1) / mc::EST_TILE;
             n_bins = ctx->n_shells * std::max(tiles, 1);
-            // the log must hold the traces of one chunk: ~64 per packet unless the caller says otherwise
-            unsigned long long cap = std::min<unsigned long long>((unsigned long long)ctx->log_capacity, (unsigned long long)chunk * 96ull + 65536ull);
+            // the log must hold the traces of one chunk, in one region per wave: 2x the measured traces per packet of the last
+            // iteration (96 per packet before anything was measured); a region that overflows falls back to atomics
+            const double per_packet = ctx->traces_per_packet > 0 ? std::max(16.0, 2.0 * ctx->traces_per_packet) : 96.0;
+            unsigned long long cap = std::min<unsigned long long>((unsigned long long)ctx->log_capacity,
+                                                                  (unsigned long long)((double)chunk * per_packet) + 65536ull);
             if (n_bins > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernels add their terms directly
             cap = std::min<unsigned long long>(cap, 0xfffffff0ull);
             for (int b = 0; b < (two_streams ? 2 : 1); ++b) {
@@ -1295,6 +1299,7 @@ int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *res)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < TARDIS_MC_N_COUNTERS; ++k) res->counters[k] = (int64_t)cnt[k];
     res->counters[TARDIS_MC_CNT_PACKETS] = ctx->n_packets;
+    if (ctx->n_packets > 0) ctx->traces_per_packet = (double)cnt[TARDIS_MC_CNT_EVENTS] / (double)ctx->n_packets;
     res->first_error_packet = -1;
     res->error_code = 0;
     if (ferr[0] != 0x7fffffffffffffffLL) {
