@@ -391,7 +391,108 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 }
             }
         }
-        // ---- macro_atom_interaction (macro_atom.py:52-104), one jump per pass, lane-per-packet
+        // ---- macro_atom_interaction (macro_atom.py:52-104), one jump of every walking packet per pass
+        if (P.line_interaction_type == 2) {
+            // macroatom mode (long jump chains over big transition tables): the wave's G-lane groups scan the blocks, G
+            // probabilities per coalesced load, accumulated in the reference's serial order (macro_atom_group() of the
+            // group kernel).  The work items and results live in LDS that the trace parameters do not need right now.
+            double *mac_event = sh.nu;
+            int *mac_row = reinterpret_cast<int *>(sh.rcp_nu), *mac_b0 = mac_row + 64;
+            int *mac_b1 = reinterpret_cast<int *>(sh.comov_nu), *mac_q = mac_b1 + 64;
+            int *res_emit = reinterpret_cast<int *>(sh.chi), *res_type = res_emit + 64;
+            int *res_b0 = reinterpret_cast<int *>(sh.rcp_chi), *res_b1 = res_b0 + 64;
+            int *res_cnt = reinterpret_cast<int *>(sh.tau_event);
+            const int gshift = lane & ~(G - 1);
+            constexpr unsigned long long GMASK = (G == 16) ? 0xffffull : ((G == 8) ? 0xffull : 0xfull);
+            for (;;) {
+                const unsigned long long items = __ballot(in_macro);
+                if (!items) break;
+                refill(__ballot(in_macro && r_cnt < 1), seeded_states);
+                const int n_items = __popcll(items);
+                if (in_macro) {
+                    mac_q[__popcll(items & ((1ull << lane) - 1ull))] = lane;
+                    mac_event[lane] = draw();
+                    mac_row[lane] = p.shell * P.n_trans;
+                    mac_b0[lane] = mb0; mac_b1[lane] = mb1;
+                }
+                // rounds of 64/G items; the first chunk of the next round's item (probabilities and transition records) is
+                // loaded before the current one is scanned
+                auto item_of = [&](int k, int &o, unsigned &row, int &b0, int &b1, double &event) {
+                    o = mac_q[k]; event = mac_event[o]; row = (unsigned)mac_row[o]; b0 = mac_b0[o]; b1 = mac_b1[o];
+                };
+                int n_o = -1, n_b0 = 0, n_b1 = 0;
+                unsigned n_row = 0;
+                double n_event = 0.0, n_pr = 0.0;
+                int4 n_rec = make_int4(0, 0, 0, 0);
+                if (lane / G < n_items) {
+                    item_of(lane / G, n_o, n_row, n_b0, n_b1, n_event);
+                    const int kk = n_b0 + j;
+                    if (kk < n_b1) { n_pr = P.prob_t[n_row + (unsigned)kk]; n_rec = P.trans_rec[(unsigned)kk]; }
+                }
+                for (int base = 0; base < n_items; base += 64 / G) {
+                    const int o = n_o, b0 = n_b0, b1 = n_b1;
+                    const unsigned row = n_row;
+                    const double event = n_event;
+                    double pr = n_pr;
+                    int4 rec = n_rec;
+                    const bool have = base + lane / G < n_items;
+                    // prefetch the next round's item
+                    n_o = -1; n_pr = 0.0; n_rec = make_int4(0, 0, 0, 0);
+                    if (base + 64 / G + lane / G < n_items) {
+                        item_of(base + 64 / G + lane / G, n_o, n_row, n_b0, n_b1, n_event);
+                        const int kk = n_b0 + j;
+                        if (kk < n_b1) { n_pr = P.prob_t[n_row + (unsigned)kk]; n_rec = P.trans_rec[(unsigned)kk]; }
+                    }
+                    if (have) {
+                        double carry = 0.0;
+                        int cnt = 0;
+                        bool found = false;
+                        int4 hit_rec = make_int4(0, 0, 0, 0);
+                        for (int b = b0; b < b1; b += G) {
+                            const int kk = b + j;
+                            const bool in = kk < b1;
+                            if (b != b0) {
+                                pr = in ? P.prob_t[row + (unsigned)kk] : 0.0;
+                                rec = in ? P.trans_rec[(unsigned)kk] : make_int4(0, 0, 0, 0);
+                            }
+                            const double acc = serial_prefix<G>(carry, pr, j);
+                            const unsigned hit = (unsigned)((__ballot(in && acc > event) >> gshift) & GMASK);
+                            if (hit) {
+                                const int f = __builtin_ctz(hit);
+                                cnt += f + 1;
+                                hit_rec.x = gbcast<G>(rec.x, f); hit_rec.y = gbcast<G>(rec.y, f);
+                                hit_rec.z = gbcast<G>(rec.z, f); hit_rec.w = gbcast<G>(rec.w, f);
+                                found = true;
+                                break;
+                            }
+                            const int n_in = min(G, b1 - b);
+                            cnt += n_in;
+                            carry = gbcast<G>(acc, n_in - 1);
+                        }
+                        if (j == 0) {
+                            if (found) {
+                                res_emit[o] = hit_rec.x; res_type[o] = hit_rec.y; res_b0[o] = hit_rec.z; res_b1[o] = hit_rec.w;
+                                res_cnt[o] = cnt;
+                            } else res_cnt[o] = -cnt - 1;
+                        }
+                    }
+                }
+                if (in_macro) {
+                    const int c = res_cnt[lane];
+                    if (c < 0) { macro += (unsigned)(-c - 1); err = ERR_MACRO_ATOM; in_macro = false; }
+                    else {
+                        macro += (unsigned)c;
+                        emit = res_emit[lane]; mb0 = res_b0[lane]; mb1 = res_b1[lane];
+                        const int tt = res_type[lane];
+                        if (tt < 0) {
+                            in_macro = false;
+                            if (tt != -1) err = ERR_UNSUPPORTED;
+                        }
+                    }
+                }
+            }
+        }
+        // downbranch (one short block): the lane walks its block itself
         while (__ballot(in_macro)) {
             refill(__ballot(in_macro && r_cnt < 2), seeded_states);
             if (in_macro) {

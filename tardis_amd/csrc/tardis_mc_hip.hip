@@ -137,7 +137,9 @@ struct TardisMcContext {
                              // seeding kernel takes, so the default stays the separate kernel.
     int pipeline_chunks = 1;  // >1: split a propagate call of the wave kernel into chunks on two streams (measured: a loss -- every chunk pays the drain of its last packets)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
-    double traces_per_packet = 0.0;  // measured by the last get_results (sizes the line-visit log of the next propagate)
+    double traces_per_packet = 0.0;  // measured by the last propagate (sizes the line-visit log of the next one)
+    unsigned long long *events_host = nullptr;  // pinned: {events counter of the last propagate, its packet count}
+    hipEvent_t ev_events = nullptr;
     std::vector<mc::WaveCold> wave_cold_host;
     int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
     // RCCL
@@ -518,6 +520,8 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->events_host) (void)hipHostFree(ctx->events_host);
+    if (ctx->ev_events) (void)hipEventDestroy(ctx->ev_events);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -968,10 +972,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     } else {
         // variant 1: cooperative kernel; MT19937 states are seeded per chunk by a lane-per-packet kernel
         long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
-        // wave-owner kernel (lane-per-packet event code, groups as sweep workers).  Its macro-atom walk is lane-per-packet,
-        // which is fine for scatter / downbranch (one short block) but not for the long jump chains of macroatom mode
-        // (random 8-byte loads instead of coalesced block reads): those, and v-packets, stay on the group kernel.
-        const bool wave_kernel = ctx->variant == 2 && !vpk && c.line_interaction_type != TARDIS_MC_LINE_MACROATOM;
+        // wave-owner kernel (lane-per-packet event code, groups as sweep and macro-atom workers); v-packets stay on the
+        // group kernel
+        const bool wave_kernel = ctx->variant == 2 && !vpk;
         if (wave_kernel && ctx->pipeline_chunks > 1 && ctx->n_packets >= (2LL << 20)) {
             // pipeline: ~pipeline_chunks chunks of at least 1 Mi packets, alternating between two streams
             const long long want = (ctx->n_packets + ctx->pipeline_chunks - 1) / ctx->pipeline_chunks;
@@ -1031,7 +1034,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         WaveKernelFn kw = nullptr;
 #define TMC_PICKW(G_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_> : mc::propagate_wave_kernel<true, false, G_>) \
                             : (trk ? mc::propagate_wave_kernel<false, true, G_> : mc::propagate_wave_kernel<false, false, G_>))
-        if (wave_kernel) kw = (ctx->group_size == 16) ? TMC_PICKW(16) : (ctx->group_size == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
+        // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel)
+        const int GW = ctx->group_size ? ctx->group_size : (ctx->n_lines <= 100000 ? 8 : 16);
+        if (wave_kernel) kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
 #undef TMC_PICKW
         // estimator log of the wave kernel (estimator_log.hpp)
         mc::EstimatorLog elog{};
@@ -1042,7 +1047,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             n_bins = ctx->n_shells * std::max(tiles, 1);
             // the log must hold the traces of one chunk, in one region per wave: 2x the measured traces per packet of the last
             // iteration (96 per packet before anything was measured); a region that overflows falls back to atomics
-            const double per_packet = ctx->traces_per_packet > 0 ? std::max(16.0, 2.0 * ctx->traces_per_packet) : 96.0;
+            if (ctx->events_host && ctx->ev_events && hipEventQuery(ctx->ev_events) == hipSuccess && ctx->events_host[1] > 0)
+                ctx->traces_per_packet = (double)ctx->events_host[0] / (double)ctx->events_host[1];
+            const double per_packet = ctx->traces_per_packet > 0 ? std::max(16.0, 2.0 * ctx->traces_per_packet) : 128.0;
             unsigned long long cap = std::min<unsigned long long>((unsigned long long)ctx->log_capacity,
                                                                   (unsigned long long)((double)chunk * per_packet) + 65536ull);
             if (n_bins > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernels add their terms directly
@@ -1171,6 +1178,17 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         }
+    }
+    {   // events per packet of this call, for the log sizing of the next one (asynchronous, pinned host memory)
+        if (!ctx->events_host) {
+            HIP_TRY(ctx, hipHostMalloc((void **)&ctx->events_host, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+            ctx->events_host[0] = ctx->events_host[1] = 0;
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_events, hipEventDisableTiming));
+        }
+        ctx->events_host[1] = (unsigned long long)ctx->n_packets;
+        HIP_TRY(ctx, hipMemcpyAsync(&ctx->events_host[0], ctx->counters.as<unsigned long long>() + TARDIS_MC_CNT_EVENTS,
+                                    sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_events, ctx->stream));
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed = true;
