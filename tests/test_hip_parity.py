@@ -321,3 +321,63 @@ def test_device_packet_spectrum_matches_numpy(engine):
         f = (nu > lo) & (nu < hi)
         assert_allclose(got[lkey], math.fsum(lum[f]), rtol=1e-12)
         assert_allclose(got[lkey], spectrum.calculate_filtered_luminosity(nu, lum, lo, hi), rtol=1e-10)
+
+
+@pytest.mark.parametrize("options", [
+    {"variant": 0}, {"variant": 1}, {"variant": 1, "group_size": 16}, {"variant": 2, "group_size": 4}, {"variant": 2, "group_size": 16},
+    {"variant": 2, "seed_in_kernel": 2},            # MT19937 states produced by seeder waves inside the propagation launch
+    {"variant": 2, "log_capacity": 4096},           # line-visit log far too small: most traces take the direct-atomics path
+    {"variant": 2, "log_capacity": 0},              # no log at all
+    {"variant": 2, "waves_per_simd": 2},
+], ids=lambda o: "-".join(f"{k}{v}" for k, v in o.items()))
+@pytest.mark.parametrize("mode", ["downbranch", "macroatom"])
+def test_kernel_variants_and_options_agree_with_the_oracle(oracle, options, mode):
+    """Every propagation kernel / option combination is the same function of its inputs: per-packet results bit-exact
+    against the oracle, estimators within the summation-order tolerance, work counters exact."""
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=17, n_packets=30_000, n_shells=12, n_lines=9_000, line_interaction_type=mode)
+    ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
+    eng = Engine(0)
+    for k, v in options.items():
+        eng.set_option(k, v)
+    eng.set_geometry(prob.geometry, prob.time_explosion)
+    eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+    eng.set_packets(prob.packet_collection)
+    for _ in range(2):      # the second iteration runs with the log sized from the first one's measured traces per packet
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        got = eng.get_results(track_last_interaction=True)
+        assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+        for f in st.LastInteractionTrackers.I64_FIELDS:
+            assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f)), f
+        for f in st.LastInteractionTrackers.F64_FIELDS:
+            assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f), equal_nan=True), f
+        assert_allclose(got.j_estimator, ref.j_estimator, rtol=EST_RTOL)
+        assert_allclose(got.nu_bar_estimator, ref.nu_bar_estimator, rtol=EST_RTOL)
+        assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+        assert_allclose(got.edotlu_estimator, ref.edotlu_estimator, rtol=EST_RTOL)
+        for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
+            assert got.counters[k] == ref.counters[k], k
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_chunked_two_stream_pipeline_matches(oracle):
+    """pipeline_chunks > 1 splits a propagate call into chunks on two streams (only for >= 2 Mi packets)."""
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=19, n_packets=(2 << 20) + 777, n_shells=6, n_lines=2_000, line_interaction_type="downbranch")
+    outs = []
+    for chunks in (1, 2):
+        eng = Engine(0)
+        eng.set_option("pipeline_chunks", chunks)
+        eng.set_option("track_last_interaction", 0)
+        eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        outs.append(eng.get_results(track_last_interaction=False))
+        assert (eng.last_kernel_times()["launches"] == 1) == (chunks == 1)
+        eng.close()
+    a, b = outs
+    assert np.array_equal(a.output_nus, b.output_nus) and np.array_equal(a.output_energies, b.output_energies)
+    assert_allclose(a.j_blue_estimator, b.j_blue_estimator, rtol=EST_RTOL)
+    assert a.counters["events"] == b.counters["events"]
