@@ -173,6 +173,9 @@ int tardis_mc_last_kernel_times(TardisMcContext *ctx, double *out_seed_ms, doubl
 /* summed duration of the line-estimator passes (record binning + accumulation) of the last propagate call; 0 when the
  * kernel variant in use updates the estimators with atomics */
 int tardis_mc_last_estimator_ms(TardisMcContext *ctx, double *out_ms);
+/* raw work counters of the last kernel launches (TARDIS_MC_CNT_*; after tardis_mc_formal_integral counters[0] is the number
+ * of resonances crossed by all rays) */
+int tardis_mc_last_counters(TardisMcContext *ctx, int64_t out_counters[TARDIS_MC_N_COUNTERS]);
 /* Per-packet results of the resident packets + estimators (re-laid to [L,S]) to caller memory. */
 int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *result);
 
@@ -210,6 +213,17 @@ int tardis_mc_packet_spectrum(TardisMcContext *ctx, double time_of_simulation, d
  * Outputs (host, any may be NULL): t_radiative[n_shells], dilution_factor[n_shells], j_blues[n_lines*n_shells] line-major. */
 int tardis_mc_radiation_field(TardisMcContext *ctx, double time_of_simulation, const double *volume, double w_epsilon,
                               int detailed_optical_window, double *t_radiative, double *dilution_factor, double *j_blues);
+
+/* ---- consumer next to the path: the formal integral of the spectrum ----------------------------------------
+ * NumbaFormalIntegrator.formal_integral / numba_formal_integral (tardis/spectrum/formal_integral/formal_integral_numba.py:
+ * 375-560, 563-642; CUDA twin formal_integral_cuda.py:272-489) on the resident geometry, line list, tau_sobolev and electron
+ * densities (set_geometry / set_opacity).  att_S_ul, Jred_lu, Jblue_lu: host, [n_shells * n_lines] in the shell-major flat
+ * order the reference passes them (make_source_function, source_function.py:71-75).  Outputs (host): luminosity_densities
+ * [n_frequencies]; intensities_nu_p [n_frequencies * n_impact_parameters] or NULL.  tardis_mc_last_propagate_ms then
+ * reports the device time of the integration kernels. */
+int tardis_mc_formal_integral(TardisMcContext *ctx, double inner_temperature, const double *frequencies, int64_t n_frequencies,
+                              const double *att_S_ul, const double *Jred_lu, const double *Jblue_lu, int64_t n_impact_parameters,
+                              double *luminosity_densities, double *intensities_nu_p);
 
 /* ---- one-shot API: the reference boundary in one call ---------------------------------------------- */
 int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const TardisMcGeometry *geometry,

@@ -34,6 +34,7 @@ SYMBOLS = {
     "tardis_mc_last_propagate_ms": (_i, [_vp, C.POINTER(C.c_double)]),
     "tardis_mc_last_kernel_times": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "tardis_mc_last_estimator_ms": (_i, [_vp, C.POINTER(C.c_double)]),
+    "tardis_mc_last_counters": (_i, [_vp, C.POINTER(C.c_int64)]),
     "tardis_mc_get_results": (_i, [_vp, _vp]),
     "tardis_mc_pcg64_seed": (_i, [C.c_uint64, C.POINTER(C.c_uint64)]),
     "tardis_mc_create_blackbody_packets": (_i, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double,
@@ -41,6 +42,7 @@ SYMBOLS = {
     "tardis_mc_get_packets": (_i, [_vp] * 6),
     "tardis_mc_packet_spectrum": (_i, [_vp, C.c_double, C.c_double, C.c_double, _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tardis_mc_radiation_field": (_i, [_vp, C.c_double, _vp, C.c_double, C.c_int, _vp, _vp, _vp]),
+    "tardis_mc_formal_integral": (_i, [_vp, C.c_double, _vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "tardis_mc_run": (_i, [_vp] * 6),
     "tardis_mc_comm_get_unique_id": (_i, [_vp]),
     "tardis_mc_comm_init": (_i, [_vp, _i, _i, _vp]),

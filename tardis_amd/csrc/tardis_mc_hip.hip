@@ -23,6 +23,7 @@
 #include "estimator_log.hpp"
 #include "propagate_wave.hpp"
 #include "packet_source.hpp"
+#include "formal_integral.hpp"
 
 namespace {
 
@@ -1244,6 +1245,18 @@ int tardis_mc_last_kernel_times(TardisMcContext *ctx, double *out_seed_ms, doubl
     return TARDIS_MC_OK;
 }
 
+int tardis_mc_last_counters(TardisMcContext *ctx, int64_t out_counters[TARDIS_MC_N_COUNTERS])
+{
+    if (!ctx || !out_counters) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->counters.p) return fail(ctx, TARDIS_MC_ERR_STATE, "no work counters yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long cnt[TARDIS_MC_N_COUNTERS];
+    HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < TARDIS_MC_N_COUNTERS; ++k) out_counters[k] = (int64_t)cnt[k];
+    return TARDIS_MC_OK;
+}
+
 int tardis_mc_last_estimator_ms(TardisMcContext *ctx, double *out_ms)
 {
     if (!ctx || !out_ms) return TARDIS_MC_ERR_INVALID_ARGUMENT;
@@ -1450,6 +1463,62 @@ int tardis_mc_radiation_field(TardisMcContext *ctx, double time_of_simulation, c
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     work.release(); out_t.release();
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_formal_integral(TardisMcContext *ctx, double inner_temperature, const double *frequencies, int64_t n_frequencies,
+                              const double *att_S_ul, const double *Jred_lu, const double *Jblue_lu, int64_t n_impact_parameters,
+                              double *luminosity_densities, double *intensities_nu_p)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_geometry || !ctx->have_opacity)
+        return fail(ctx, TARDIS_MC_ERR_STATE, "formal integral needs set_geometry and set_opacity");
+    if (!frequencies || !att_S_ul || !Jred_lu || !Jblue_lu || !luminosity_densities || n_frequencies < 0 || n_impact_parameters < 2 ||
+        n_frequencies > (1LL << 30) || n_impact_parameters > 65535)
+        return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "invalid formal integral arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t S = (size_t)ctx->n_shells, L = (size_t)ctx->n_lines, n_nu = (size_t)n_frequencies, N = (size_t)n_impact_parameters;
+    if (n_nu == 0) return TARDIS_MC_OK;
+    DevBuf work;  // [exp_tau | att | jred | jblue | freqs | z | I | Lum] doubles, then sid / n_int ints
+    const size_t n_d = 4 * S * L + n_nu + N * 2 * S + n_nu * N + n_nu;
+    HIP_TRY(ctx, work.ensure(n_d * sizeof(double) + (N * 2 * S + N) * sizeof(int)));
+    double *d_exp = work.as<double>(), *d_att = d_exp + S * L, *d_jred = d_att + S * L, *d_jblue = d_jred + S * L,
+           *d_freq = d_jblue + S * L, *d_z = d_freq + n_nu, *d_I = d_z + N * 2 * S, *d_lum = d_I + n_nu * N;
+    int *d_sid = reinterpret_cast<int *>(d_lum + n_nu), *d_nint = d_sid + N * 2 * S;
+    HIP_TRY(ctx, hipMemcpyAsync(d_att, att_S_ul, S * L * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_jred, Jred_lu, S * L * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_jblue, Jblue_lu, S * L * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_freq, frequencies, n_nu * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    if (S * L > 0)
+        hipLaunchKernelGGL(mc::fi_exp_tau_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->tau_t.as<double>(), (long long)(S * L), d_exp);
+    hipLaunchKernelGGL(mc::fi_intersections_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, ctx->stream, (int)S,
+                       ctx->r_inner.as<double>(), ctx->r_outer.as<double>(), ctx->t_exp, (int)N, d_z, d_sid, d_nint);
+    std::vector<double> r_last(1);
+    HIP_TRY(ctx, hipMemcpyAsync(r_last.data(), ctx->r_outer.as<double>() + (S - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    mc::FormalIntegralArgs a{};
+    a.n_shells = (int)S; a.n_lines = (int)L; a.n_nu = (int)n_nu; a.N = (int)N;
+    a.t_exp = ctx->t_exp; a.inner_temperature = inner_temperature; a.radius_max = r_last[0];
+    a.sigma_thomson = 6.652458734e-25;  // SIGMA_THOMSON, transport/montecarlo/configuration/constants.py:3 (astropy const13)
+    a.r_inner = ctx->r_inner.as<double>(); a.nu_line = ctx->nu_line.as<double>(); a.n_e = ctx->n_e.as<double>();
+    a.exp_tau = d_exp; a.att_S_ul = d_att; a.Jred_lu = d_jred; a.Jblue_lu = d_jblue; a.frequencies = d_freq;
+    a.z = d_z; a.sid = d_sid; a.n_int = d_nint; a.intensities_nu_p = d_I;
+    HIP_TRY(ctx, ctx->counters.ensure(TARDIS_MC_N_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->counters.p, 0, TARDIS_MC_N_COUNTERS * sizeof(unsigned long long), ctx->stream));
+    a.line_steps = ctx->counters.as<unsigned long long>();  // counters[0] (line visits) = resonances crossed by the rays
+    hipLaunchKernelGGL(mc::fi_rays_kernel, dim3((unsigned)((n_nu + 63) / 64), (unsigned)N), dim3(64), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(mc::fi_trapezoid_kernel, dim3((unsigned)((n_nu + 63) / 64)), dim3(64), 0, ctx->stream, d_I, (int)n_nu, (int)N,
+                       a.radius_max, d_lum);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = true;
+    ctx->chunks_timed = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(luminosity_densities, d_lum, n_nu * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (intensities_nu_p) HIP_TRY(ctx, hipMemcpyAsync(intensities_nu_p, d_I, n_nu * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    work.release();
     return TARDIS_MC_OK;
 }
 

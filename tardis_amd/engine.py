@@ -176,6 +176,27 @@ class Engine:
                                                       jb.ctypes.data if jb is not None else None), "radiation_field")
         return {"t_radiative": t_rad, "dilution_factor": w, "j_blues": jb}
 
+    def last_counters(self) -> dict:
+        out = (C.c_int64 * len(_abi.COUNTER_NAMES))()
+        self._check(self._L.tardis_mc_last_counters(self._h, out), "last_counters")
+        return dict(zip(_abi.COUNTER_NAMES, [int(v) for v in out]))
+
+    def formal_integral(self, inner_temperature: float, frequencies, att_S_ul, Jred_lu, Jblue_lu, n_impact_parameters: int = 1000,
+                        want_intensities: bool = False):
+        """numba_formal_integral (spectrum/formal_integral/formal_integral_numba.py:375-560) on the resident geometry / opacity:
+        returns (luminosity_densities, intensities_nu_p or None)."""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64).ravel()
+        freqs, att, jred, jblue = f(frequencies), f(att_S_ul), f(Jred_lu), f(Jblue_lu)
+        n = self.n_shells * self.n_lines
+        if att.size != n or jred.size != n or jblue.size != n:
+            raise ValueError("att_S_ul / Jred_lu / Jblue_lu must have n_shells * n_lines entries (shell-major)")
+        lum = np.empty(freqs.size)
+        inten = np.empty((freqs.size, int(n_impact_parameters))) if want_intensities else None
+        self._check(self._L.tardis_mc_formal_integral(self._h, float(inner_temperature), freqs.ctypes.data, freqs.size, att.ctypes.data,
+                                                      jred.ctypes.data, jblue.ctypes.data, int(n_impact_parameters), lum.ctypes.data,
+                                                      inten.ctypes.data if inten is not None else None), "formal_integral")
+        return lum, inten
+
     # -- multi-GPU
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -53,7 +53,7 @@ def install():
 
     # ---- numba
     def _njit(*a, **k):
-        if len(a) == 1 and callable(a[0]) and not k:
+        if len(a) == 1 and callable(a[0]):  # @njit, @njit(**opts) applied directly: njit(f, **opts)
             return a[0]
         return lambda f: f
 

@@ -17,7 +17,7 @@ def kernel_stats(db):
     for name, n, tot, avg, mn, mx in rows:
         print(f"{name[:70]:70s} {n:6d} {tot:16d} {avg:14.1f} {100.0 * tot / total:10.2f} {mn:12d} {mx:12d}")
     q = ("select s.kernel_name, s.arch_vgpr_count, s.accum_vgpr_count, s.sgpr_count, s.group_segment_size, s.private_segment_size "
-         "from rocpd_info_kernel_symbol s where s.kernel_name like '%propagate_wave%' or s.kernel_name like '%seed%' or s.kernel_name like '%accumulate%' or s.kernel_name like '%bin_%'")
+         "from rocpd_info_kernel_symbol s where s.kernel_name like '%propagate_wave%' or s.kernel_name like '%seed%' or s.kernel_name like '%accumulate%' or s.kernel_name like '%bin_%' or s.kernel_name like '%fi_%'")
     for r in c.execute(q):
         print("resources:", r)
 
@@ -28,7 +28,7 @@ def pmc_sums(db):
          "join rocpd_info_pmc p on e.pmc_id=p.id join rocpd_kernel_dispatch d on e.event_id=d.event_id "
          "join rocpd_info_kernel_symbol s on d.kernel_id=s.id group by s.kernel_name, p.name")
     for name, counter, n, total in c.execute(q):
-        if any(k in name for k in ("propagate", "seed", "accumulate", "bin_", "packet_source", "spectrum", "radfield")):
+        if any(k in name for k in ("propagate", "seed", "accumulate", "bin_", "packet_source", "spectrum", "radfield", "fi_")):
             print(f"{name[:60]:60s} {counter:24s} dispatches={n:3d} sum_over_dispatches={total:.6g} per_dispatch={total / n:.6g}")
 
 

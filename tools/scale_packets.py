@@ -1,5 +1,6 @@
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tardis_amd import synthetic
 from tardis_amd.engine import Engine
 for n in (2_500_000, 5_000_000, 10_000_000, 20_000_000):

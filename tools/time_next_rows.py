@@ -6,7 +6,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tardis_amd import spectrum, synthetic  # noqa: E402
 from tardis_amd.engine import Engine  # noqa: E402
 

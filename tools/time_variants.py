@@ -1,6 +1,7 @@
 """Time one propagate step for engine option combinations:  python tools/time_variants.py [config] key=value[,key=value...] ..."""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tardis_amd import synthetic
 from tardis_amd.engine import Engine
 
