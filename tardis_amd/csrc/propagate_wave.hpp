@@ -30,7 +30,7 @@ namespace mc {
 
 constexpr int WV_STATE_STRIDE = 640;  // words between the MT19937 states of two packets: 2560 B, so that no two packets share a
                                       // 128-byte cache line (a wave never touches memory a seeder may still be writing)
-constexpr int WV_RING = 8;  // look-ahead doubles per packet (power of two; a refill adds 4, so it needs r_cnt <= 4).  16 with 8-double
+constexpr int WV_RING = 8, WV_RING_VPK = 16;  // look-ahead doubles per packet (power of two; a refill adds 4, so it needs r_cnt <= 4).  16 with 8-double
                             // refills was measured: fewer refill rounds, but the extra 4 KiB of LDS costs the 12th wave of the CU
 enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3 };
 constexpr int RES_PENDING = -1;
@@ -39,7 +39,6 @@ constexpr int RES_PENDING = -1;
 struct WaveShared {
     double nu[64], rcp_nu[64], comov_nu[64], chi[64], rcp_chi[64], tau_event[64], d_cont0[64];
     double d_boundary[64];  // in: boundary distance of the prepared trace; out: distance of the event found
-    double ring[WV_RING][64];
     int cursor[64], rowfast[64];  // first line of the trace; shell * n_lines | exact-division fast path << 31
     int res_info[64], res_line[64];
     int queue[64];                // lanes whose prepared trace waits for a worker group
@@ -54,10 +53,11 @@ struct LaneTracker {
     int shell_id, line_absorb_id, line_emit_id, interaction_type;
 };
 
-template <bool FULL>
+template <bool FULL, bool VPK>
 __host__ __device__ constexpr size_t wave_kernel_lds_bytes(int n_shells)
 {
-    return sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0) + 2 * (size_t)n_shells * sizeof(double);
+    return sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0) + (size_t)(VPK ? WV_RING_VPK : WV_RING) * 64 * sizeof(double) +
+           2 * (size_t)n_shells * sizeof(double);
 }
 
 // Kernel arguments.  Only what the sweep loop touches is passed by value (-> SGPRs); everything the event phase needs is
@@ -200,13 +200,105 @@ __device__ __forceinline__ void seed_role(const WaveCold *__restrict__ W, const 
     }
 }
 
-template <bool FULL, bool TRACK, int G>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
+// ---- v-packets (packets/virtual_packet.py:82-386), lane-per-packet: every lane traces the v-packets of ITS packet one after
+// the other, drawing from its own stream in the reference's order -- so, unlike the group kernel, nothing has to be
+// predicted or re-traced.  The per-shell work is vp_trace()'s of the group kernel: the stopping line is located through
+// the frequency-bucket index and pinned with the reference's own predicate, the optical depths are summed in the
+// reference's order.  The volley is a flat per-lane state machine (one shell crossing per pass of the wave-level loop; a
+// lane that finishes a v-packet starts its next one in the following pass), so lanes never wait for the longest
+// v-packet of a round.  `draws_left` bounds the Russian-roulette draws one v-packet may take from the lane's LDS ring.
+struct VpState {
+    double r, mu, nu, energy, tau, mu0;
+    int shell, next_line;
+};
+
+// one shell crossing of trace_vpacket (:82-244): returns 1 when the v-packet has left the grid / died, 0 to go on, < 0 error
+template <bool FULL, typename Draw>
+__device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, int &draws_left, VpState &v, unsigned &vvisits)
+{
+    const int L = P.n_lines;
+    const double t = P.t_exp;
+    int status = ST_IN_PROCESS;
+    // trace_vpacket_within_shell (:82-175)
+    double d_boundary;
+    int delta;
+    distance_boundary(v.r, v.mu, P.r_inner[v.shell], P.r_outer[v.shell], d_boundary, delta);
+    const double chi_e = P.n_e[v.shell] * P.sigma_thomson;
+    const double velocity = v.r / t;
+    const double dop = doppler_factor<FULL>(velocity, v.mu);
+    const double comov_nu = v.nu * dop;
+    double chi_cont = chi_e;
+    if (FULL) chi_cont *= dop;
+    double tau_shell = chi_cont * d_boundary;
+    const unsigned row = (unsigned)v.shell * (unsigned)L;
+    const int start = v.next_line;
+    if (start < L) {
+        double d_line;
+        if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, start == L - 1, P.nu_line[(unsigned)start], t, d_line)) return ERR_MONTECARLO;
+        int e = start;
+        if (!(d_boundary <= d_line)) {
+            const double nu_thr = comov_nu - d_boundary * P.rcp_tc * v.nu;
+            long long kk = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
+            kk = kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
+            e = max(P.bucket_first[kk], start + 1);
+            if (e > L - 1) e = L - 1;
+            for (;;) {
+                if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, e == L - 1, P.nu_line[(unsigned)e], t, d_line)) return ERR_MONTECARLO;
+                if (d_boundary <= d_line || e == L - 1) break;
+                ++e;
+            }
+            bool stops = d_boundary <= d_line;
+            while (e > start + 1) {
+                double d_prev;
+                if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, false, P.nu_line[(unsigned)(e - 1)], t, d_prev)) return ERR_MONTECARLO;
+                if (!(d_boundary <= d_prev)) break;
+                --e;
+                stops = true;
+            }
+            if (!stops) e = L;
+        }
+        // serial-order sum of tau over [start, e)
+        const double *__restrict__ trow = P.tau_t + row;
+        int k = start;
+        const int e_sum = min(e, L);
+        for (; k + 4 <= e_sum; k += 4) {
+            const double t0 = trow[(unsigned)k], t1 = trow[(unsigned)k + 1], t2 = trow[(unsigned)k + 2], t3 = trow[(unsigned)k + 3];
+            tau_shell += t0; tau_shell += t1; tau_shell += t2; tau_shell += t3;
+        }
+        for (; k < e_sum; ++k) tau_shell += trow[(unsigned)k];
+        vvisits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
+        v.next_line = e;
+    }
+    // trace_vpacket (:179-244)
+    v.tau += tau_shell;
+    cross_shell(v.shell, status, delta, P.n_shells);
+    if (v.tau > P.tau_russian) {
+        if (draws_left <= 0) return ERR_UNSUPPORTED;
+        --draws_left;
+        const double ev = draw();
+        if (ev > P.survival_probability) {
+            v.energy = 0.0;
+            status = ST_EMITTED;
+        } else {
+            v.energy = v.energy / P.survival_probability * mcm::exp(-v.tau);
+            v.tau = 0.0;
+        }
+    }
+    const double new_r = sqrt(v.r * v.r + d_boundary * d_boundary + 2.0 * v.r * d_boundary * v.mu);
+    v.mu = (v.mu * v.r + d_boundary) / new_r;
+    v.r = new_r;
+    return status == ST_EMITTED ? 1 : 0;
+}
+
+template <bool FULL, bool TRACK, int G, bool VPK>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3 : 4, VPK ? 3 : 4))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     WaveShared &sh = *reinterpret_cast<WaveShared *>(lds_raw);
     WaveSharedFull &shf = *reinterpret_cast<WaveSharedFull *>(lds_raw + sizeof(WaveShared));
-    double *lds_J = reinterpret_cast<double *>(lds_raw + sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0));
+    constexpr int RING = VPK ? WV_RING_VPK : WV_RING;  // look-ahead doubles per packet
+    double *ring = reinterpret_cast<double *>(lds_raw + sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0));  // [RING][64]
+    double *lds_J = ring + RING * 64;
     double *lds_nubar = lds_J + H.n_shells;
     const int lane = threadIdx.x;  // one wave per workgroup
     if ((int)blockIdx.x < W->n_seeders) {
@@ -229,6 +321,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     int pflags = 0;       // bit 0: exact-division fast path is safe; bits 1-2: delta_shell + 1
     int r_gpos = 0, r_head = 0, r_cnt = 0;  // MT19937: next state block to regenerate; LDS ring of tempered doubles
     unsigned draws = 0, events = 0, macro = 0;
+    unsigned long long vvisits_total = 0;  // v-packet work counters
+    unsigned vcount = 0;
+    int vseq = 0;  // v-packets emitted so far by this lane's packet
     int trk_count = 0, trk_boundary = 0;  // interactions_count, boundary crossings since the last interaction
     LaneTracker trk;
     trk.radius = trk.before_nu = trk.before_mu = trk.before_energy = trk.after_mu = 0.0;
@@ -241,8 +336,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     unsigned dbg_rounds = 0;  // wave-uniform profiling counter: sweep rounds (reported through counters[7])
 
     auto draw = [&]() {
-        const double v = sh.ring[r_head][lane];
-        r_head = (r_head + 1) & (WV_RING - 1);
+        const double v = ring[r_head * 64 + lane];
+        r_head = (r_head + 1) & (RING - 1);
         --r_cnt;
         ++draws;
         return v;
@@ -265,7 +360,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             const unsigned long long served = need & ~rest;
             need = rest;
             const int src = my_owner >= 0 ? my_owner : lane;
-            const int o_pkt = __shfl(pkt, src), o_gpos = __shfl(r_gpos, src), o_tail = __shfl((r_head + r_cnt) & (WV_RING - 1), src);
+            const int o_pkt = __shfl(pkt, src), o_gpos = __shfl(r_gpos, src), o_tail = __shfl((r_head + r_cnt) & (RING - 1), src);
             if (my_owner >= 0) {
                 uint32_t *st = seeded_states + (size_t)o_pkt * WV_STATE_STRIDE;
                 const int k = o_gpos + sj;
@@ -278,7 +373,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 __builtin_nontemporal_store(v, &st[k]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 const uint32_t nb = (uint32_t)__shfl_down((int)v, 1, 8);
-                if (!(sj & 1)) sh.ring[(o_tail + (sj >> 1)) & (WV_RING - 1)][my_owner] = GroupRng<8>::to_double(v, nb);
+                if (!(sj & 1)) ring[((o_tail + (sj >> 1)) & (RING - 1)) * 64 + my_owner] = GroupRng<8>::to_double(v, nb);
             }
             if ((served >> lane) & 1ull) {
                 r_cnt += 4;
@@ -301,6 +396,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         int err = 0, type = 0, emit = -1, mb0 = 0, mb1 = 0;
         double inv_new = 1.0, distance = 0.0;
         bool in_macro = false, interacted = false;
+        bool want_volley = false;  // this lane's packet launches a volley of v-packets in this pass
         // ---- log the line visits of the finished traces (update_line_estimators, deferred: estimator_log.hpp)
         {
             int n_visit = 0, start = 0;
@@ -536,6 +632,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 }
             }
             state = WS_NEED_TRACE;
+            // volley after a line or electron-scattering interaction (classic/packet_propagation.py:201-244)
+            if (VPK && interacted && !err) want_volley = true;
             if (err || p.status != ST_IN_PROCESS) {
                 const long long i = chunk_first + pkt;
                 const DeviceProblem *C = P.cold;
@@ -628,11 +726,100 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                             p.next_line_id = lo;
                         }
                         state = WS_NEED_TRACE;
+                        if (VPK) { vseq = 0; want_volley = true; }  // volley at launch (classic/packet_propagation.py:109-118)
                     }
                 }
             }
         }
         if (__ballot(state != WS_DONE) == 0ull) break;
+        if (VPK) {
+            // ---- trace_vpacket_volley (virtual_packet.py:248-386): all lanes with a volley trace their i-th v-packet together
+            const int n_v = (int)P.n_vpackets;
+            bool in_volley = want_volley && state == WS_NEED_TRACE && !(p.nu < P.spawn_start || p.nu > P.spawn_end) && n_v > 0;
+            double mu_min = 0.0, beta_inner = 0.0, mu_bin = 0.0, r_dop = 1.0;
+            bool on_inner = false;
+            int verr = 0;
+            if (in_volley) {
+                const double r_in0 = P.r_inner[0];
+                if (p.r > r_in0) {
+                    const double r_inner_over_r = r_in0 / p.r;
+                    mu_min = -sqrt(1 - r_inner_over_r * r_inner_over_r);
+                    if (FULL) mu_min = aberration_lf_to_cmf(p.r, t, mu_min);
+                } else {
+                    on_inner = true;
+                    if (FULL) {
+                        const double inv_c = 1 / C_LIGHT;
+                        const double inv_t = 1 / t;
+                        beta_inner = r_in0 * inv_t * inv_c;
+                    }
+                }
+                mu_bin = (1.0 - mu_min) / (double)n_v;
+                r_dop = doppler_factor<FULL>(p.r / t, p.mu);
+            }
+            const DeviceProblem *C = P.cold;
+            int vi = 0;            // index of the v-packet this lane is tracing / will start next
+            bool tracing = false;  // a v-packet is under way
+            int draws_left = 0;
+            unsigned my_visits = 0;
+            VpState vs;
+            vs.r = vs.mu = vs.nu = vs.energy = vs.tau = vs.mu0 = 0.0; vs.shell = 0; vs.next_line = 0;
+            while (__ballot(in_volley)) {
+                // a v-packet takes its mu draw and at most RING - 5 roulette draws from the ring filled before it starts
+                refill(__ballot(in_volley && !tracing && r_cnt <= RING - 4), seeded_states);
+                if (in_volley) {
+                    if (!tracing) {
+                        draws_left = r_cnt - 1;
+                        const double xi = draw();
+                        double v_mu = mu_min + (double)vi * mu_bin + xi * mu_bin;
+                        double weight;
+                        if (on_inner) {
+                            if (!FULL) weight = 2 * v_mu / (double)n_v;
+                            else weight = 2 * (v_mu + beta_inner) / (2 * beta_inner + 1) / (double)n_v;
+                        } else
+                            weight = (1 - mu_min) / (double)(2 * n_v);
+                        if (FULL) v_mu = aberration_cmf_to_lf(p.r, t, v_mu);
+                        const double v_dop = doppler_factor<FULL>(p.r / t, v_mu);
+                        const double ratio = r_dop / v_dop;
+                        vs.r = p.r; vs.mu = v_mu; vs.mu0 = v_mu;  // the log records the (aberrated) launch direction (:337-340,375)
+                        vs.nu = p.nu * ratio;
+                        vs.energy = p.energy * weight * ratio;
+                        vs.tau = 0.0; vs.shell = p.shell; vs.next_line = p.next_line_id;
+                        my_visits = 0;
+                        tracing = true;
+                    }
+                    const int st = vp_shell_step<FULL>(P, draw, draws_left, vs, my_visits);
+                    if (st < 0) { verr = st; in_volley = false; }
+                    else if (st == 1) {
+                        const double v_energy = vs.energy * mcm::exp(-vs.tau);
+                        ++vcount;
+                        vvisits_total += my_visits;
+                        // add_vpacket_collection_to_histogram (modes/montecarlo_transport.py:166-195)
+                        if (!(vs.nu < P.grid0 || vs.nu > P.grid_last)) {
+                            const long long idx = (long long)floor((vs.nu - P.grid0) / P.delta_nu);
+                            atomic_add_f64(&P.vhist[idx], v_energy);
+                        }
+                        if (C->vlog_count) {
+                            const unsigned long long slot = atomicAdd(C->vlog_count, 1ull);
+                            if ((long long)slot < C->vlog_capacity) {
+                                C->vlog_packet[slot] = chunk_first + pkt; C->vlog_seq[slot] = vseq;
+                                C->vlog_nu[slot] = vs.nu; C->vlog_energy[slot] = v_energy; C->vlog_mu[slot] = vs.mu0; C->vlog_r[slot] = p.r;
+                            }
+                        }
+                        ++vseq;
+                        ++vi;
+                        tracing = false;
+                        if (vi == n_v) in_volley = false;
+                    }
+                }
+            }
+            if (verr) {  // the reference raises: the packet ends with the error code
+                const long long i = chunk_first + pkt;
+                atomicMin(&C->first_error[0], i);
+                C->out_nu[i] = (double)verr;
+                C->out_e[i] = -99.0;
+                state = WS_NEED_PACKET;
+            }
+        }
         // ---- prologue of the next trace (trace_packet, modes/homologous_rad_packet_transport.py:30-98)
         refill(__ballot(state == WS_NEED_TRACE && r_cnt < 1), seeded_states);
         {
@@ -730,15 +917,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
     // counters: wave-reduce, one atomic each
     unsigned long long v = (j == 0) ? visits : 0ull;  // group-uniform: count once per group
-    unsigned long long e = events, m = macro, d = draws;
+    unsigned long long e = events, m = macro, d = draws, vv = vvisits_total, vc = vcount;
     for (int off = 32; off > 0; off >>= 1) {
         v += __shfl_down(v, off); e += __shfl_down(e, off); m += __shfl_down(m, off); d += __shfl_down(d, off);
+        vv += __shfl_down(vv, off); vc += __shfl_down(vc, off);
     }
     if (lane == 0) {
         atomicAdd(&C->counters[0], v);
         atomicAdd(&C->counters[1], e);
         atomicAdd(&C->counters[2], m);
         atomicAdd(&C->counters[5], d);
+        if (VPK) { atomicAdd(&C->counters[3], vv); atomicAdd(&C->counters[4], vc); atomicAdd(&C->counters[7], vv); }
         if (H.debug_flags & 16) atomicAdd(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
     }
 }

@@ -123,7 +123,7 @@ struct TardisMcContext {
     mc::DeviceProblem problem_host{};
     long long chunk_packets = 16LL << 20;  // packets per seeded-state chunk (2496 B each) of the cooperative kernel
     // launch geometry
-    int variant = 2;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel (v-packets: variant 1)
+    int variant = -1;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel; -1: automatic (2, but 1 with v-packets)
     int blocks_per_cu = 16;
     int debug_flags = 0;
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
@@ -953,7 +953,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // init_err lives on this stack frame
     // the cooperative kernel relies on a sorted line list (bucket index, monotone stopping predicate); anything else --
     // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
-    const bool cooperative = (ctx->variant == 1 || ctx->variant == 2) && ctx->lines_sorted && (!vpk || c.number_of_vpackets <= 32);
+    // automatic choice: the wave-owner kernel, except with v-packets, where the group kernel's volleys are (still) faster
+    const int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets <= 32) ? 1 : 2);
+    const bool cooperative = ctx->lines_sorted && (variant == 2 || (variant == 1 && (!vpk || c.number_of_vpackets <= 32)));
 
     if (!cooperative) {
         // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment
@@ -973,9 +975,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     } else {
         // variant 1: cooperative kernel; MT19937 states are seeded per chunk by a lane-per-packet kernel
         long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
-        // wave-owner kernel (lane-per-packet event code, groups as sweep and macro-atom workers); v-packets stay on the
-        // group kernel
-        const bool wave_kernel = ctx->variant == 2 && !vpk;
+        // wave-owner kernel (lane-per-packet event code and v-packet volleys, groups as sweep and macro-atom workers)
+        const bool wave_kernel = variant == 2;
         if (wave_kernel && ctx->pipeline_chunks > 1 && ctx->n_packets >= (2LL << 20)) {
             // pipeline: ~pipeline_chunks chunks of at least 1 Mi packets, alternating between two streams
             const long long want = (ctx->n_packets + ctx->pipeline_chunks - 1) / ctx->pipeline_chunks;
@@ -1023,7 +1024,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         using KernelFn = void (*)(mc::GroupArgs, uint32_t *, long long, long long);
         KernelFn k;
         const bool full = c.enable_full_relativity != 0, trk = ctx->track;
-        const size_t wave_lds = full ? mc::wave_kernel_lds_bytes<true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false>(ctx->n_shells);
+        const size_t wave_lds = vpk ? (full ? mc::wave_kernel_lds_bytes<true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, true>(ctx->n_shells))
+                                    : (full ? mc::wave_kernel_lds_bytes<true, false>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false>(ctx->n_shells));
         if (wave_kernel && wave_lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
         const int wave_waves_per_cu = std::max(1, std::min(ctx->waves_per_simd > 0 ? 4 * ctx->waves_per_simd : 16, (int)((160 * 1024) / wave_lds)));
 #define TMC_PICK2(G_, V_) (full ? (trk ? mc::propagate_group_kernel<true, true, G_, 256, 4, V_> : mc::propagate_group_kernel<true, false, G_, 256, 4, V_>) \
@@ -1033,11 +1035,13 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 #undef TMC_PICK2
         using WaveKernelFn = void (*)(mc::WaveHot, const mc::WaveCold *);
         WaveKernelFn kw = nullptr;
-#define TMC_PICKW(G_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_> : mc::propagate_wave_kernel<true, false, G_>) \
-                            : (trk ? mc::propagate_wave_kernel<false, true, G_> : mc::propagate_wave_kernel<false, false, G_>))
+#define TMC_PICKW2(G_, V_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_, V_> : mc::propagate_wave_kernel<true, false, G_, V_>) \
+                                 : (trk ? mc::propagate_wave_kernel<false, true, G_, V_> : mc::propagate_wave_kernel<false, false, G_, V_>))
+#define TMC_PICKW(G_) (vpk ? TMC_PICKW2(G_, true) : TMC_PICKW2(G_, false))
         // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel)
         const int GW = ctx->group_size ? ctx->group_size : (ctx->n_lines <= 100000 ? 8 : 16);
         if (wave_kernel) kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
+#undef TMC_PICKW2
 #undef TMC_PICKW
         // estimator log of the wave kernel (estimator_log.hpp)
         mc::EstimatorLog elog{};

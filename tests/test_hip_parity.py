@@ -95,6 +95,22 @@ def test_device_mt19937_matches_numpy_stream(engine, oracle, seed):
 
 @pytest.mark.parametrize("name", _golden.CASES)
 def test_hip_matches_oracle_and_reference_on_golden_cases(engine, oracle, name):
+    _check_golden_case(engine, oracle, name)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("name", [n for n in _golden.CASES if "_nv2" in n or "_nv3" in n])
+def test_every_kernel_variant_on_vpacket_golden_cases(engine, oracle, name, variant):
+    """The automatic choice sends v-packet problems to the group kernel; the wave-owner kernel's lane-per-packet volleys and
+    the lane kernel must reproduce the same goldens (incl. the consolidated v-packet log)."""
+    engine.set_option("variant", variant)
+    try:
+        _check_golden_case(engine, oracle, name)
+    finally:
+        engine.set_option("variant", -1)
+
+
+def _check_golden_case(engine, oracle, name):
     prob, g = _golden.load_case(name)
     ref = run_oracle(oracle, prob)
     hist, vt, eb, el, trk, counters = run_hip(engine, prob)
