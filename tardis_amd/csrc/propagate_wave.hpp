@@ -28,8 +28,7 @@
 
 namespace mc {
 
-constexpr int WV_STATE_STRIDE = 640;  // words between the MT19937 states of two packets: 2560 B, so that no two packets share a
-                                      // 128-byte cache line (a wave never touches memory a seeder may still be writing)
+constexpr int WV_STATE_STRIDE = 624;  // words between the MT19937 states of two packets
 constexpr int WV_RING = 8, WV_RING_VPK = 16;  // look-ahead doubles per packet (power of two; a refill adds 4, so it needs r_cnt <= 4).  16 with 8-double
                             // refills was measured: fewer refill rounds, but the extra 4 KiB of LDS costs the 12th wave of the CU
 enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3 };
@@ -42,6 +41,7 @@ struct WaveShared {
     int cursor[64], rowfast[64];  // first line of the trace; shell * n_lines | exact-division fast path << 31
     int res_info[64], res_line[64];
     int queue[64];                // lanes whose prepared trace waits for a worker group
+    unsigned rng_a[64], rng_b[64];  // lazy MT19937 seeding: init_genrand words mt[k] and mt[k+397] of the next block to regenerate
 };
 struct WaveSharedFull {  // only read by the full-relativity sweep
     double r[64], mu[64];
@@ -73,11 +73,10 @@ struct WaveCold {
     EstimatorLog log;
     uint32_t *seeded_states;
     long long chunk_first, chunk_count;
-    // in-kernel seeding: the first n_seeders workgroups of the grid produce the MT19937 start states, 64 packets at a time,
-    // and raise seed_flags[tile]; the propagating waves wait for the flag of a packet's tile before they touch its state
     const uint32_t *seeds;
-    unsigned *seed_flags;
-    int n_seeders;
+    // lazy seeding: only word 397 of every packet's init_genrand sequence is precomputed (seed_checkpoint_kernel); the two
+    // windows of initial words a regeneration step needs are continued from mt[k] and mt[k+397] inside the refill
+    const uint32_t *seed_checkpoint;
 };
 
 // One worker slot of a group: the trace it is sweeping (group-uniform values) and this lane's line of the current chunk.
@@ -162,42 +161,15 @@ __device__ __forceinline__ void sweep_step(const WaveHot &P, SweepSlot &s, const
     }
 }
 
-// Seeder role: init_genrand (numpy legacy seeding, mt19937.c) for 64 packets per pass, one packet per lane; the serial
-// recurrence leaves no parallelism inside a packet.  Words go through an LDS tile so that 16 lanes write 64 contiguous
-// bytes of one packet's state.  Seeder waves never wait for anybody, so the waves waiting on seed_flags always get served.
-__device__ __forceinline__ void seed_role(const WaveCold *__restrict__ W, const int lane, unsigned char *lds_raw)
+// init_genrand up to word 397, one packet per lane: the only part of the start state that is ever precomputed in the lazy mode
+__global__ void __launch_bounds__(256) seed_checkpoint_kernel(const uint32_t *__restrict__ seeds, uint32_t *__restrict__ checkpoint,
+                                                              long long first, long long count)
 {
-    uint32_t (*tile)[17] = reinterpret_cast<uint32_t (*)[17]>(lds_raw);  // 64 x 17 words
-    const long long n = W->chunk_count;
-    const long long n_tiles = (n + 63) / 64;
-    const uint32_t *__restrict__ seeds = W->seeds + W->chunk_first;
-    for (long long tl = blockIdx.x; tl < n_tiles; tl += W->n_seeders) {
-        const long long i = tl * 64 + lane;
-        uint32_t x = i < n ? seeds[i] : 0u;
-        uint32_t *__restrict__ out = W->seeded_states + (size_t)tl * 64 * WV_STATE_STRIDE;
-        const int n_valid = (int)min(64LL, n - tl * 64);
-        for (int base = 0; base < MT_N; base += 16) {
-#pragma unroll
-            for (int w = 0; w < 16; ++w) {
-                const int k = base + w;
-                if (k > 0) x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
-                tile[lane][w] = x;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pk = (lane >> 4) + 4 * r;
-                // agent-scope (write-through) stores: the states must be visible to the other XCDs without an L2 write-back
-                if (pk < n_valid)
-                    __hip_atomic_store(&out[(size_t)pk * WV_STATE_STRIDE + base + (lane & 15)], tile[pk][lane & 15], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every state word has been written through
-        if (lane == 0) __hip_atomic_store(&W->seed_flags[tl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t x = seeds[first + i];
+    for (int k = 1; k <= 397; ++k) x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
+    checkpoint[i] = x;
 }
 
 // ---- v-packets (packets/virtual_packet.py:82-386), lane-per-packet: every lane traces the v-packets of ITS packet one after
@@ -301,10 +273,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     double *lds_J = ring + RING * 64;
     double *lds_nubar = lds_J + H.n_shells;
     const int lane = threadIdx.x;  // one wave per workgroup
-    if ((int)blockIdx.x < W->n_seeders) {
-        seed_role(W, lane, lds_raw);
-        return;
-    }
     for (int s = lane; s < 2 * H.n_shells; s += 64) lds_J[s] = 0.0;
 
     const int j = lane & (G - 1);
@@ -342,44 +310,58 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         ++draws;
         return v;
     };
-    // wave-uniform: give every lane of `need` four more doubles (8 stream words, regenerated in place by an 8-lane
-    // subgroup with coalesced accesses; 624 = 78 * 8, so a block never wraps)
+    // Give every lane of `need` four more doubles: the lane regenerates the next 8 words of ITS packet's MT19937 state itself
+    // (genrand's twist, mt19937.c) and parks the 4 tempered doubles in its LDS ring.  During the first pass over the state
+    // the initial words it needs -- init_genrand's mt[k0 .. k0+8] and mt[k0+397 .. k0+404] -- are continued from the two
+    // words kept in LDS (lazy seeding: only mt[397] was precomputed), so no memory is read at all for the first 112
+    // doubles of a packet; the regenerated words go to the packet's state buffer, from which later blocks read them.
     auto refill = [&](unsigned long long need, uint32_t *seeded_states) {
-        const int sj = lane & 7;
-        while (need) {
-            int my_owner = -1;
-            unsigned long long rest = need;
+        if (!((need >> lane) & 1ull)) return;
+        uint32_t *st = seeded_states + (size_t)pkt * WV_STATE_STRIDE;
+        const int k0 = r_gpos & 0x3ff;
+        uint32_t wa[9], wc[8];
+        if (!(r_gpos >> 16)) {  // first pass over the state
+            uint32_t w = sh.rng_a[lane];  // mt[k0]
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (rest) {
-                    const int o = __builtin_ctzll(rest);
-                    rest &= rest - 1;
-                    if ((lane >> 3) == q) my_owner = o;
-                }
+            for (int i = 0; i < 9; ++i) {
+                wa[i] = w;
+                if (i < 8) w = 1812433253u * (w ^ (w >> 30)) + (uint32_t)(k0 + i + 1);
             }
-            const unsigned long long served = need & ~rest;
-            need = rest;
-            const int src = my_owner >= 0 ? my_owner : lane;
-            const int o_pkt = __shfl(pkt, src), o_gpos = __shfl(r_gpos, src), o_tail = __shfl((r_head + r_cnt) & (RING - 1), src);
-            if (my_owner >= 0) {
-                uint32_t *st = seeded_states + (size_t)o_pkt * WV_STATE_STRIDE;
-                const int k = o_gpos + sj;
-                const int k1 = (k + 1 == MT_N) ? 0 : k + 1;
-                const int km = (k + 397 >= MT_N) ? k + 397 - MT_N : k + 397;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t a = __builtin_nontemporal_load(&st[k]), b = __builtin_nontemporal_load(&st[k1]), c = __builtin_nontemporal_load(&st[km]);
-                const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-                const uint32_t v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                __builtin_nontemporal_store(v, &st[k]);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                const uint32_t nb = (uint32_t)__shfl_down((int)v, 1, 8);
-                if (!(sj & 1)) ring[((o_tail + (sj >> 1)) & (RING - 1)) * 64 + my_owner] = GroupRng<8>::to_double(v, nb);
+            sh.rng_a[lane] = w;  // mt[k0 + 8]
+            if (k0 + 8 == MT_N) wa[8] = st[0];  // word 623 pairs with the NEW word 0
+            uint32_t wb = sh.rng_b[lane];  // mt[k0 + 397]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                wc[i] = wb;
+                wb = 1812433253u * (wb ^ (wb >> 30)) + (uint32_t)(k0 + 397 + i + 1);
             }
-            if ((served >> lane) & 1ull) {
-                r_cnt += 4;
-                r_gpos = (r_gpos + 8 == MT_N) ? 0 : r_gpos + 8;
+            sh.rng_b[lane] = wb;  // mt[k0 + 405]
+            if (k0 + 397 + 7 >= MT_N) {  // (part of) the second window has wrapped: those are regenerated words
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (k0 + 397 + i >= MT_N) wc[i] = st[k0 + 397 + i - MT_N];
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wa[i] = st[(k0 + i == MT_N) ? 0 : k0 + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wc[i] = st[(k0 + 397 + i >= MT_N) ? k0 + 397 + i - MT_N : k0 + 397 + i];
         }
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t y = (wa[i] & 0x80000000u) | (wa[i + 1] & 0x7fffffffu);
+            v[i] = wc[i] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        v4u *dst = reinterpret_cast<v4u *>(st + k0);  // 32-byte aligned: k0 is a multiple of 8
+        v4u lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
+        dst[0] = lo4; dst[1] = hi4;
+        const int tail = (r_head + r_cnt) & (RING - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ring[((tail + q) & (RING - 1)) * 64 + lane] = GroupRng<8>::to_double(v[2 * q], v[2 * q + 1]);
+        r_cnt += 4;
+        r_gpos = (k0 + 8 == MT_N) ? 0x10000 : r_gpos + 8;  // bit 16: the state has been regenerated once
     };
 
     for (;;) {
@@ -687,15 +669,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     else {
                         pkt = (int)mine;
                         r_gpos = r_head = r_cnt = 0;
-                        if (W->n_seeders > 0) {  // the start state of this packet comes from a seeder wave of this launch
-                            unsigned spins = 0;
-                            // (relaxed polling: nobody on this CU / XCD has touched the packet's cache lines before, so there is nothing
-                            // stale to invalidate, and an acquire per fetch would flush the L1 under the sweeps)
-                            while (__hip_atomic_load(&W->seed_flags[mine >> 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-                                __builtin_amdgcn_s_sleep(8);
-                                if (++spins > (1u << 22)) { atomicMin(&P.cold->first_error[0], chunk_first + mine); break; }
-                            }
-                        }
+                        sh.rng_a[lane] = W->seeds[chunk_first + mine];  // mt[0]
+                        sh.rng_b[lane] = W->seed_checkpoint[mine];      // mt[397]
                         const long long i = chunk_first + mine;
                         const DeviceProblem *C = P.cold;
                         p.r = C->r0[i]; p.mu = C->mu0[i]; p.nu = C->nu0[i]; p.energy = C->e0[i];

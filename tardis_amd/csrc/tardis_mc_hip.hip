@@ -132,10 +132,8 @@ struct TardisMcContext {
     // chunk overlap the propagation of its neighbours
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], seeded_states2, next_packet2, wave_cold_dev, seed_flags[2];
-    int seed_in_kernel = 0;  // >0: the MT19937 start states are produced by this many seeder waves per CU inside the propagation launch.
-                             // Measured: the 25 GB of state writes slow the (latency-bound) sweeps by exactly the time the separate
-                             // seeding kernel takes, so the default stays the separate kernel.
+    DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], seeded_states2, next_packet2, wave_cold_dev;
+    DevBuf seed_chk[2];  // wave kernel: word 397 of every packet's init_genrand sequence (lazy MT19937 seeding)
     int pipeline_chunks = 1;  // >1: split a propagate call of the wave kernel into chunks on two streams (measured: a loss -- every chunk pays the drain of its last packets)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
     double traces_per_packet = 0.0;  // measured by the last propagate (sizes the line-visit log of the next one)
@@ -515,7 +513,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
         ctx->log_sorted[b].release();
     }
     ctx->seeded_states2.release(); ctx->next_packet2.release(); ctx->wave_cold_dev.release();
-    ctx->seed_flags[0].release(); ctx->seed_flags[1].release();
+    ctx->seed_chk[0].release(); ctx->seed_chk[1].release();
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
@@ -544,7 +542,6 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
-    else if (n == "seed_in_kernel") ctx->seed_in_kernel = std::max(0, std::min(16, (int)value));
     else if (n == "pipeline_chunks") ctx->pipeline_chunks = std::max(1, (int)value);
     else if (n == "log_capacity") ctx->log_capacity = std::max<long long>(0, value);
     else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
@@ -1129,14 +1126,15 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 ctx->ev_chunk.push_back(e);
             }
             HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci], st));
-            const bool seeders = wave_kernel && ctx->seed_in_kernel;
-            const long long n_tiles = (count + 63) / 64;
-            if (seeders) {
-                HIP_TRY(ctx, ctx->seed_flags[b].ensure((size_t)n_tiles * sizeof(unsigned)));
-                HIP_TRY(ctx, hipMemsetAsync(ctx->seed_flags[b].p, 0, (size_t)n_tiles * sizeof(unsigned), st));
+            if (wave_kernel) {
+                // lazy seeding: only word 397 of every start state is precomputed; the refills continue the init_genrand chains
+                HIP_TRY(ctx, ctx->seed_chk[b].ensure((size_t)count * sizeof(uint32_t)));
+                hipLaunchKernelGGL(mc::seed_checkpoint_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                                   ctx->seeds.as<uint32_t>(), ctx->seed_chk[b].as<uint32_t>(), first, count);
+                HIP_TRY(ctx, hipGetLastError());
             } else {
                 hipLaunchKernelGGL(mc::seed_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
-                                   ctx->seeds.as<uint32_t>(), seeded, first, count, wave_kernel ? mc::WV_STATE_STRIDE : mc::MT_N);
+                                   ctx->seeds.as<uint32_t>(), seeded, first, count, mc::MT_N);
                 HIP_TRY(ctx, hipGetLastError());
             }
             HIP_TRY(ctx, hipMemsetAsync(next_packet, 0, sizeof(unsigned long long), st));
@@ -1147,24 +1145,22 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             if (wave_kernel) {
                 const long long want_waves = (count + 63) / 64;
                 const int waves = (int)std::max<long long>(1, std::min<long long>(want_waves, (long long)cus * wave_waves_per_cu));
-                const int n_seed_waves = seeders ? (int)std::min<long long>((long long)cus * ctx->seed_in_kernel, n_tiles) : 0;
                 mc::EstimatorLog lg = elog;
-                HIP_TRY(ctx, set_log_regions(lg, b, waves + n_seed_waves, st));
+                HIP_TRY(ctx, set_log_regions(lg, b, waves, st));
                 // cold arguments of this launch: one device slot per chunk (the host copies stay alive in ctx->wave_cold_host)
                 if ((int)ctx->wave_cold_host.size() <= ci) ctx->wave_cold_host.resize(ci + 1);
                 mc::WaveCold &wc = ctx->wave_cold_host[ci];
                 wc.P = P; wc.P.next_packet = next_packet; wc.log = lg; wc.seeded_states = seeded;
                 wc.chunk_first = first; wc.chunk_count = count;
                 wc.seeds = ctx->seeds.as<uint32_t>();
-                wc.seed_flags = seeders ? ctx->seed_flags[b].as<unsigned>() : nullptr;
-                wc.n_seeders = n_seed_waves;
+                wc.seed_checkpoint = ctx->seed_chk[b].as<uint32_t>();
                 mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci;
                 HIP_TRY(ctx, hipMemcpyAsync(wc_dev, &wc, sizeof(mc::WaveCold), hipMemcpyHostToDevice, st));
                 mc::WaveHot hot{};
                 hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
                 hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
                 hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
-                hipLaunchKernelGGL(kw, dim3(waves + wc.n_seeders), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
+                hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));
                 HIP_TRY(ctx, estimator_passes(lg, b, st));

@@ -341,7 +341,6 @@ def test_device_packet_spectrum_matches_numpy(engine):
 
 @pytest.mark.parametrize("options", [
     {"variant": 0}, {"variant": 1}, {"variant": 1, "group_size": 16}, {"variant": 2, "group_size": 4}, {"variant": 2, "group_size": 16},
-    {"variant": 2, "seed_in_kernel": 2},            # MT19937 states produced by seeder waves inside the propagation launch
     {"variant": 2, "log_capacity": 4096},           # line-visit log far too small: most traces take the direct-atomics path
     {"variant": 2, "log_capacity": 0},              # no log at all
     {"variant": 2, "waves_per_simd": 2},
