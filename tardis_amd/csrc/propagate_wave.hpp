@@ -57,7 +57,7 @@ template <bool FULL, bool VPK>
 __host__ __device__ constexpr size_t wave_kernel_lds_bytes(int n_shells)
 {
     return sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0) + (size_t)(VPK ? WV_RING_VPK : WV_RING) * 64 * sizeof(double) +
-           2 * (size_t)n_shells * sizeof(double);
+           (size_t)(VPK ? 5 : 2) * (size_t)n_shells * sizeof(double);  // J, nu_bar (+ r_inner, r_outer, n_e for the v-packets)
 }
 
 // Kernel arguments.  Only what the sweep loop touches is passed by value (-> SGPRs); everything the event phase needs is
@@ -184,62 +184,114 @@ struct VpState {
     int shell, next_line;
 };
 
-// one shell crossing of trace_vpacket (:82-244): returns 1 when the v-packet has left the grid / died, 0 to go on, < 0 error
+// one shell crossing of trace_vpacket (:82-244): returns 1 when the v-packet has left the grid / died, 0 to go on, < 0 error.
+// Written branch-light so that the lanes of a wave (each on a different v-packet) stay converged: the stopping line is
+// pinned with a fixed number of predicate evaluations around the frequency-bucket guess (a loop only if that was not
+// enough), and the optical depths are added in wave-uniform chunks of 8 with exact no-op adds (+0.0) in the lanes that
+// have fewer lines.  rcp_nu = RN(1 / v.nu) serves the exact 3-instruction division (mc_device.hpp) of the resonance
+// distances; v.nu is constant along a v-packet.
 template <bool FULL, typename Draw>
-__device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, int &draws_left, VpState &v, unsigned &vvisits)
+__device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, int &draws_left, VpState &v, double rcp_nu, bool fast_nu,
+                                             const double *__restrict__ geo /* LDS: r_inner | r_outer | n_e */, unsigned &vvisits)
 {
-    const int L = P.n_lines;
+    const int L = P.n_lines, S = P.n_shells;
     const double t = P.t_exp;
     int status = ST_IN_PROCESS;
+    const unsigned row = (unsigned)v.shell * (unsigned)L;
+    const int start = v.next_line;
+    // The step is bound by the latency of its dependent, uncoalesced loads, so everything whose address is known now is
+    // requested first: the line at `start` and -- speculatively -- the first eight optical depths of the sum.
+    const int start_c = min(start, L - 1);
+    const double *__restrict__ trow = P.tau_t + row + (unsigned)start_c;
+    const int last_ok = L - 1 - start_c;  // highest in-bounds offset
+    const double nl_start = P.nu_line[(unsigned)start_c];
+    double tv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tv[k] = trow[(unsigned)min(k, last_ok)];
     // trace_vpacket_within_shell (:82-175)
     double d_boundary;
     int delta;
-    distance_boundary(v.r, v.mu, P.r_inner[v.shell], P.r_outer[v.shell], d_boundary, delta);
-    const double chi_e = P.n_e[v.shell] * P.sigma_thomson;
+    distance_boundary(v.r, v.mu, geo[v.shell], geo[S + v.shell], d_boundary, delta);
+    const double chi_e = geo[2 * S + v.shell] * P.sigma_thomson;
     const double velocity = v.r / t;
     const double dop = doppler_factor<FULL>(velocity, v.mu);
     const double comov_nu = v.nu * dop;
     double chi_cont = chi_e;
     if (FULL) chi_cont *= dop;
     double tau_shell = chi_cont * d_boundary;
-    const unsigned row = (unsigned)v.shell * (unsigned)L;
-    const int start = v.next_line;
+    // calculate_distance_line (calculate_distances.py:66-112) of line k (frequency nl) for this v-packet
+    auto d_line_of = [&](int k, double nl) -> double {
+        if (FULL) {
+            double d;
+            distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, k == L - 1, nl, t, d);
+            return d;
+        }
+        const double nu_diff = comov_nu - nl;
+        const double q = (fast_nu && mid_range(nu_diff)) ? exact_div<true>(nu_diff, v.nu, rcp_nu) : nu_diff / v.nu;
+        const double d = (fabs(q) < CLOSE_LINE_THRESHOLD) ? 0.0 : q * C_LIGHT * t;
+        return (k == L - 1) ? MISS_DISTANCE : d;
+    };
+    int n_sum = 0;
     if (start < L) {
         double d_line;
-        if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, start == L - 1, P.nu_line[(unsigned)start], t, d_line)) return ERR_MONTECARLO;
+        // the reference evaluates line `start` first and raises there if it lies blueward of the packet (lines further
+        // down the sorted list can then not raise: their nu_diff is larger)
+        if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, start == L - 1, nl_start, t, d_line)) return ERR_MONTECARLO;
         int e = start;
         if (!(d_boundary <= d_line)) {
+            // first line after `start` whose resonance lies at or beyond the shell boundary (monotone along the list):
+            // the frequency-bucket index gives a guess, a window of four lines around it is tested in one round trip
             const double nu_thr = comov_nu - d_boundary * P.rcp_tc * v.nu;
             long long kk = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
             kk = kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
             e = max(P.bucket_first[kk], start + 1);
             if (e > L - 1) e = L - 1;
-            for (;;) {
-                if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, e == L - 1, P.nu_line[(unsigned)e], t, d_line)) return ERR_MONTECARLO;
-                if (d_boundary <= d_line || e == L - 1) break;
-                ++e;
+            const int w0 = max(e - 1, start + 1);
+            bool sw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = min(w0 + i, L - 1);
+                sw[i] = d_boundary <= d_line_of(k, P.nu_line[(unsigned)k]);
             }
-            bool stops = d_boundary <= d_line;
-            while (e > start + 1) {
-                double d_prev;
-                if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, false, P.nu_line[(unsigned)(e - 1)], t, d_prev)) return ERR_MONTECARLO;
-                if (!(d_boundary <= d_prev)) break;
-                --e;
-                stops = true;
+            bool resolved = false, stops = false;
+            if (sw[0]) {
+                if (w0 == start + 1) { e = w0; stops = true; resolved = true; }
+                else e = w0;  // the first stopping line lies before the window
+            } else if (sw[1]) { e = min(w0 + 1, L - 1); stops = true; resolved = true; }
+            else if (sw[2]) { e = min(w0 + 2, L - 1); stops = true; resolved = true; }
+            else if (sw[3]) { e = min(w0 + 3, L - 1); stops = true; resolved = true; }
+            else e = min(w0 + 3, L - 1);  // beyond the window
+            if (!resolved) {  // the bucket guess was further off: the reference's walk, forward then backward
+                for (;;) {
+                    d_line = d_line_of(e, P.nu_line[(unsigned)e]);
+                    if (d_boundary <= d_line || e == L - 1) break;
+                    ++e;
+                }
+                stops = d_boundary <= d_line;
+                while (e > start + 1) {
+                    if (!(d_boundary <= d_line_of(e - 1, P.nu_line[(unsigned)(e - 1)]))) break;
+                    --e;
+                    stops = true;
+                }
             }
-            if (!stops) e = L;
+            if (!stops) e = L;  // (the reference then sums every line)
         }
-        // serial-order sum of tau over [start, e)
-        const double *__restrict__ trow = P.tau_t + row;
-        int k = start;
-        const int e_sum = min(e, L);
-        for (; k + 4 <= e_sum; k += 4) {
-            const double t0 = trow[(unsigned)k], t1 = trow[(unsigned)k + 1], t2 = trow[(unsigned)k + 2], t3 = trow[(unsigned)k + 3];
-            tau_shell += t0; tau_shell += t1; tau_shell += t2; tau_shell += t3;
-        }
-        for (; k < e_sum; ++k) tau_shell += trow[(unsigned)k];
+        n_sum = min(e, L) - start;
         vvisits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
         v.next_line = e;
+    }
+    // serial-order sum of tau over [start, start + n_sum): wave-uniform chunks of 8 (the first one was requested at the top),
+    // +0.0 where a lane has no line left
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tau_shell += (k < n_sum) ? tv[k] : 0.0;
+    for (int base = 8; __ballot(base < n_sum); base += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int o = base + k;
+            tv[k] = (o < n_sum) ? trow[(unsigned)min(o, last_ok)] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tau_shell += tv[k];
     }
     // trace_vpacket (:179-244)
     v.tau += tau_shell;
@@ -272,6 +324,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     double *ring = reinterpret_cast<double *>(lds_raw + sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0));  // [RING][64]
     double *lds_J = ring + RING * 64;
     double *lds_nubar = lds_J + H.n_shells;
+    double *lds_geo = lds_nubar + H.n_shells;  // VPK only: r_inner | r_outer | n_e
+    if (VPK) {
+        for (int s = threadIdx.x; s < H.n_shells; s += 64) {
+            lds_geo[s] = W->P.r_inner[s]; lds_geo[H.n_shells + s] = W->P.r_outer[s]; lds_geo[2 * H.n_shells + s] = W->P.n_e[s];
+        }
+    }
     const int lane = threadIdx.x;  // one wave per workgroup
     for (int s = lane; s < 2 * H.n_shells; s += 64) lds_J[s] = 0.0;
 
@@ -737,6 +795,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             int draws_left = 0;
             unsigned my_visits = 0;
             VpState vs;
+            double v_rcp_nu = 0.0;
+            bool v_fast = false;
             vs.r = vs.mu = vs.nu = vs.energy = vs.tau = vs.mu0 = 0.0; vs.shell = 0; vs.next_line = 0;
             while (__ballot(in_volley)) {
                 // a v-packet takes its mu draw and at most RING - 5 roulette draws from the ring filled before it starts
@@ -757,12 +817,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         const double ratio = r_dop / v_dop;
                         vs.r = p.r; vs.mu = v_mu; vs.mu0 = v_mu;  // the log records the (aberrated) launch direction (:337-340,375)
                         vs.nu = p.nu * ratio;
+                        v_rcp_nu = 1.0 / vs.nu;
+                        v_fast = mid_range(vs.nu);
                         vs.energy = p.energy * weight * ratio;
                         vs.tau = 0.0; vs.shell = p.shell; vs.next_line = p.next_line_id;
                         my_visits = 0;
                         tracing = true;
                     }
-                    const int st = vp_shell_step<FULL>(P, draw, draws_left, vs, my_visits);
+                    const int st = vp_shell_step<FULL>(P, draw, draws_left, vs, v_rcp_nu, v_fast, lds_geo, my_visits);
                     if (st < 0) { verr = st; in_volley = false; }
                     else if (st == 1) {
                         const double v_energy = vs.energy * mcm::exp(-vs.tau);
