@@ -60,6 +60,13 @@ __host__ __device__ constexpr size_t wave_kernel_lds_bytes(int n_shells)
            (size_t)(VPK ? 5 : 2) * (size_t)n_shells * sizeof(double);  // J, nu_bar (+ r_inner, r_outer, n_e for the v-packets)
 }
 
+// result of one (possibly speculative) v-packet trace, handed from the worker lane to the owner lane through global scratch
+struct __attribute__((aligned(16))) VpResult {
+    double nu, energy, mu0;
+    int used, visits, err, pad;
+};
+constexpr int VP_ROUND = 6;  // v-packets of one packet per round of a pooled volley (2 * VP_ROUND draws must fit the ring)
+
 // Kernel arguments.  Only what the sweep loop touches is passed by value (-> SGPRs); everything the event phase needs is
 // read through `cold` (a device copy) at the top of every pass, so that it does not occupy scalar registers -- and, once
 // those run out, VGPR lanes -- during the sweeps.
@@ -77,6 +84,7 @@ struct WaveCold {
     // lazy seeding: only word 397 of every packet's init_genrand sequence is precomputed (seed_checkpoint_kernel); the two
     // windows of initial words a regeneration step needs are continued from mt[k] and mt[k+397] inside the refill
     const uint32_t *seed_checkpoint;
+    VpResult *vp_scratch;  // [waves][64 * VP_ROUND]
 };
 
 // One worker slot of a group: the trace it is sweeping (group-uniform values) and this lane's line of the current chunk.
@@ -350,6 +358,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     unsigned long long vvisits_total = 0;  // v-packet work counters
     unsigned vcount = 0;
     int vseq = 0;  // v-packets emitted so far by this lane's packet
+    unsigned pred_bits = 0;  // roulette predictor of the volleys: bit i = v-packet i of the last volley took a roulette draw
+    unsigned long long vtraced_total = 0;
     int trk_count = 0, trk_boundary = 0;  // interactions_count, boundary crossings since the last interaction
     LaneTracker trk;
     trk.radius = trk.before_nu = trk.before_mu = trk.before_energy = trk.after_mu = 0.0;
@@ -759,7 +769,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             p.next_line_id = lo;
                         }
                         state = WS_NEED_TRACE;
-                        if (VPK) { vseq = 0; want_volley = true; }  // volley at launch (classic/packet_propagation.py:109-118)
+                        if (VPK) { vseq = 0; pred_bits = 0; want_volley = true; }  // volley at launch (classic/packet_propagation.py:109-118)
                     }
                 }
             }
@@ -790,63 +800,146 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 r_dop = doppler_factor<FULL>(p.r / t, p.mu);
             }
             const DeviceProblem *C = P.cold;
-            int vi = 0;            // index of the v-packet this lane is tracing / will start next
-            bool tracing = false;  // a v-packet is under way
-            int draws_left = 0;
-            unsigned my_visits = 0;
-            VpState vs;
-            double v_rcp_nu = 0.0;
-            bool v_fast = false;
-            vs.r = vs.mu = vs.nu = vs.energy = vs.tau = vs.mu0 = 0.0; vs.shell = 0; vs.next_line = 0;
+            // Pooled volley.  The v-packets of ALL volleys of the wave are work items for ALL 64 lanes, so a packet deep in
+            // the ejecta (many shells per v-packet) does not make the lanes of shallow packets wait.  The n_v mu-draws and
+            // the Russian-roulette draws come from the parent's stream in sequence, so an item reads its draws at the
+            // position predicted by the packet's bit mask of "v-packet i played roulette last time" (same mu bin, same
+            // optical depth to first order -- the group kernel's predictor); the owner lane then commits its items in
+            // order up to and including the first one whose draw consumption differs from the prediction, and the rest is
+            // traced again in the next round from the corrected stream position.
+            VpResult *vres = W->vp_scratch + (size_t)blockIdx.x * (64 * VP_ROUND);
+            unsigned short *items = reinterpret_cast<unsigned short *>(sh.nu);  // [64 * VP_ROUND] over sh.nu | sh.rcp_nu (idle now)
+            int vdone = 0;  // v-packets of this lane's volley committed so far
             while (__ballot(in_volley)) {
-                // a v-packet takes its mu draw and at most RING - 5 roulette draws from the ring filled before it starts
-                refill(__ballot(in_volley && !tracing && r_cnt <= RING - 4), seeded_states);
-                if (in_volley) {
-                    if (!tracing) {
-                        draws_left = r_cnt - 1;
-                        const double xi = draw();
-                        double v_mu = mu_min + (double)vi * mu_bin + xi * mu_bin;
-                        double weight;
-                        if (on_inner) {
-                            if (!FULL) weight = 2 * v_mu / (double)n_v;
-                            else weight = 2 * (v_mu + beta_inner) / (2 * beta_inner + 1) / (double)n_v;
-                        } else
-                            weight = (1 - mu_min) / (double)(2 * n_v);
-                        if (FULL) v_mu = aberration_cmf_to_lf(p.r, t, v_mu);
-                        const double v_dop = doppler_factor<FULL>(p.r / t, v_mu);
-                        const double ratio = r_dop / v_dop;
-                        vs.r = p.r; vs.mu = v_mu; vs.mu0 = v_mu;  // the log records the (aberrated) launch direction (:337-340,375)
-                        vs.nu = p.nu * ratio;
-                        v_rcp_nu = 1.0 / vs.nu;
-                        v_fast = mid_range(vs.nu);
-                        vs.energy = p.energy * weight * ratio;
-                        vs.tau = 0.0; vs.shell = p.shell; vs.next_line = p.next_line_id;
-                        my_visits = 0;
-                        tracing = true;
-                    }
-                    const int st = vp_shell_step<FULL>(P, draw, draws_left, vs, v_rcp_nu, v_fast, lds_geo, my_visits);
-                    if (st < 0) { verr = st; in_volley = false; }
-                    else if (st == 1) {
-                        const double v_energy = vs.energy * mcm::exp(-vs.tau);
-                        ++vcount;
-                        vvisits_total += my_visits;
-                        // add_vpacket_collection_to_histogram (modes/montecarlo_transport.py:166-195)
-                        if (!(vs.nu < P.grid0 || vs.nu > P.grid_last)) {
-                            const long long idx = (long long)floor((vs.nu - P.grid0) / P.delta_nu);
-                            atomic_add_f64(&P.vhist[idx], v_energy);
+                const int n_round = in_volley ? min(VP_ROUND, n_v - vdone) : 0;
+                for (;;) {  // one mu draw and one roulette draw per v-packet of the round must be in the ring
+                    const unsigned long long need = __ballot(in_volley && r_cnt < 2 * n_round);
+                    if (!need) break;
+                    refill(need, seeded_states);
+                }
+                // work items of the round: (owner lane << 8) | slot
+                int incl = n_round;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int up = __shfl_up(incl, off);
+                    if (lane >= off) incl += up;
+                }
+                const int item0 = incl - n_round;
+                const int n_items = __shfl(incl, 63);
+                for (int sl = 0; sl < n_round; ++sl) items[item0 + sl] = (unsigned short)((lane << 8) | sl);
+                // ---- workers
+                int next = 0;
+                bool tracing = false;
+                int w_owner = 0, w_item = 0, w_q = 0, w_used = 0, w_avail = 0, w_head = 0;
+                unsigned my_visits = 0;
+                VpState vs;
+                double v_rcp_nu = 0.0;
+                bool v_fast = false;
+                vs.r = vs.mu = vs.nu = vs.energy = vs.tau = vs.mu0 = 0.0; vs.shell = 0; vs.next_line = 0;
+                for (;;) {
+                    const unsigned long long free_l = __ballot(!tracing);
+                    const int n_take = min(__popcll(free_l), n_items - next);
+                    const int rank = __popcll(free_l & ((1ull << lane) - 1ull));
+                    const bool take = !tracing && rank < n_take;
+                    const int my_item = next + rank;
+                    next += n_take;
+                    if (!__ballot(tracing || take)) break;
+                    if (n_take > 0) {  // wave-uniform: some lane starts an item and needs its owner's state
+                        const int it = take ? (int)items[my_item] : 0;
+                        const int o = take ? (it >> 8) : lane;
+                        const int slot = it & 0xff;
+                        const double f_r = __shfl(p.r, o), f_nu = __shfl(p.nu, o), f_energy = __shfl(p.energy, o), f_rdop = __shfl(r_dop, o);
+                        const double f_mu_min = __shfl(mu_min, o), f_mu_bin = __shfl(mu_bin, o), f_beta = __shfl(beta_inner, o);
+                        const int f_shell = __shfl(p.shell, o), f_line = __shfl(p.next_line_id, o), f_inner = __shfl((int)on_inner, o);
+                        const int f_vdone = __shfl(vdone, o), f_head = __shfl(r_head, o), f_cnt = __shfl(r_cnt, o);
+                        const unsigned f_pred = (unsigned)__shfl((int)pred_bits, o);
+                        if (take) {
+                            const int i = f_vdone + slot;  // index of the v-packet in its volley
+                            const unsigned before = (f_pred >> f_vdone) & ((1u << slot) - 1u);  // predicted roulette draws of slots < slot
+                            const int q = slot + __popc(before);
+                            const double xi = ring[((f_head + q) & (RING - 1)) * 64 + o];
+                            w_owner = o; w_item = my_item; w_q = q + 1; w_used = 0; w_avail = f_cnt; w_head = f_head;
+                            double v_mu = f_mu_min + (double)i * f_mu_bin + xi * f_mu_bin;
+                            double weight;
+                            if (f_inner) {
+                                if (!FULL) weight = 2 * v_mu / (double)n_v;
+                                else weight = 2 * (v_mu + f_beta) / (2 * f_beta + 1) / (double)n_v;
+                            } else
+                                weight = (1 - f_mu_min) / (double)(2 * n_v);
+                            if (FULL) v_mu = aberration_cmf_to_lf(f_r, t, v_mu);
+                            const double v_dop = doppler_factor<FULL>(f_r / t, v_mu);
+                            const double ratio = f_rdop / v_dop;
+                            vs.r = f_r; vs.mu = v_mu; vs.mu0 = v_mu;  // the log records the (aberrated) launch direction (:337-340,375)
+                            vs.nu = f_nu * ratio;
+                            v_rcp_nu = 1.0 / vs.nu;
+                            v_fast = mid_range(vs.nu);
+                            vs.energy = f_energy * weight * ratio;
+                            vs.tau = 0.0; vs.shell = f_shell; vs.next_line = f_line;
+                            my_visits = 0;
+                            tracing = true;
                         }
-                        if (C->vlog_count) {
-                            const unsigned long long slot = atomicAdd(C->vlog_count, 1ull);
-                            if ((long long)slot < C->vlog_capacity) {
-                                C->vlog_packet[slot] = chunk_first + pkt; C->vlog_seq[slot] = vseq;
-                                C->vlog_nu[slot] = vs.nu; C->vlog_energy[slot] = v_energy; C->vlog_mu[slot] = vs.mu0; C->vlog_r[slot] = p.r;
+                    }
+                    if (tracing) {
+                        auto wdraw = [&]() {
+                            const double d = ring[((w_head + w_q + w_used) & (RING - 1)) * 64 + w_owner];
+                            ++w_used;
+                            return d;
+                        };
+                        int draws_left = w_avail - (w_q + w_used);
+                        const int st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, v_rcp_nu, v_fast, lds_geo, my_visits);
+                        if (st != 0) {
+                            VpResult r;
+                            r.nu = vs.nu; r.energy = st == 1 ? vs.energy * mcm::exp(-vs.tau) : 0.0; r.mu0 = vs.mu0;
+                            r.used = w_used; r.visits = (int)my_visits; r.err = st < 0 ? st : 0; r.pad = 0;
+                            vres[w_item] = r;
+                            tracing = false;
+                        }
+                    }
+                }
+                // ---- the owners validate and commit their items in order
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (in_volley) {
+                    bool valid = true;
+                    int n_ok = 0, consumed = 0;
+                    unsigned obs = 0;
+                    for (int sl = 0; sl < n_round; ++sl) {
+                        const VpResult r = vres[item0 + sl];
+                        vtraced_total += (unsigned)r.visits;
+                        if (r.used > 0) obs |= 1u << sl;  // learn from every trace of the round, committed or not
+                        if (valid) {
+                            if (r.err) { verr = r.err; valid = false; }
+                            else {
+                                ++vcount;
+                                vvisits_total += (unsigned)r.visits;
+                                // add_vpacket_collection_to_histogram (modes/montecarlo_transport.py:166-195)
+                                if (!(r.nu < P.grid0 || r.nu > P.grid_last)) {
+                                    const long long idx = (long long)floor((r.nu - P.grid0) / P.delta_nu);
+                                    atomic_add_f64(&P.vhist[idx], r.energy);
+                                }
+                                if (C->vlog_count) {
+                                    const unsigned long long slot = atomicAdd(C->vlog_count, 1ull);
+                                    if ((long long)slot < C->vlog_capacity) {
+                                        C->vlog_packet[slot] = chunk_first + pkt; C->vlog_seq[slot] = vseq;
+                                        C->vlog_nu[slot] = r.nu; C->vlog_energy[slot] = r.energy; C->vlog_mu[slot] = r.mu0; C->vlog_r[slot] = p.r;
+                                    }
+                                }
+                                ++vseq;
+                                ++n_ok;
+                                consumed += 1 + r.used;
+                                // it started from the right stream position itself; the items after it did only if it
+                                // consumed what was predicted
+                                if (r.used != (int)((pred_bits >> (vdone + sl)) & 1u)) valid = false;
                             }
                         }
-                        ++vseq;
-                        ++vi;
-                        tracing = false;
-                        if (vi == n_v) in_volley = false;
                     }
+                    const unsigned seen = (1u << n_round) - 1u;
+                    pred_bits = (pred_bits & ~(seen << vdone)) | (obs << vdone);
+                    r_head = (r_head + consumed) & (RING - 1);
+                    r_cnt -= consumed;
+                    draws += (unsigned)consumed;
+                    vdone += n_ok;
+                    if (verr || vdone == n_v) in_volley = false;
                 }
             }
             if (verr) {  // the reference raises: the packet ends with the error code
@@ -954,17 +1047,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     }
     // counters: wave-reduce, one atomic each
     unsigned long long v = (j == 0) ? visits : 0ull;  // group-uniform: count once per group
-    unsigned long long e = events, m = macro, d = draws, vv = vvisits_total, vc = vcount;
+    unsigned long long e = events, m = macro, d = draws, vv = vvisits_total, vc = vcount, vt = vtraced_total;
     for (int off = 32; off > 0; off >>= 1) {
         v += __shfl_down(v, off); e += __shfl_down(e, off); m += __shfl_down(m, off); d += __shfl_down(d, off);
-        vv += __shfl_down(vv, off); vc += __shfl_down(vc, off);
+        vv += __shfl_down(vv, off); vc += __shfl_down(vc, off); vt += __shfl_down(vt, off);
     }
     if (lane == 0) {
         atomicAdd(&C->counters[0], v);
         atomicAdd(&C->counters[1], e);
         atomicAdd(&C->counters[2], m);
         atomicAdd(&C->counters[5], d);
-        if (VPK) { atomicAdd(&C->counters[3], vv); atomicAdd(&C->counters[4], vc); atomicAdd(&C->counters[7], vv); }
+        if (VPK) { atomicAdd(&C->counters[3], vv); atomicAdd(&C->counters[4], vc); atomicAdd(&C->counters[7], vt); }
         if (H.debug_flags & 16) atomicAdd(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
     }
 }

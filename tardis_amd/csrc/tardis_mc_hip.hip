@@ -133,7 +133,7 @@ struct TardisMcContext {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], seeded_states2, next_packet2, wave_cold_dev;
-    DevBuf seed_chk[2];  // wave kernel: word 397 of every packet's init_genrand sequence (lazy MT19937 seeding)
+    DevBuf seed_chk[2], vp_scratch;  // wave kernel: word 397 of every packet's init_genrand sequence (lazy MT19937 seeding)
     int pipeline_chunks = 1;  // >1: split a propagate call of the wave kernel into chunks on two streams (measured: a loss -- every chunk pays the drain of its last packets)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
     double traces_per_packet = 0.0;  // measured by the last propagate (sizes the line-visit log of the next one)
@@ -513,7 +513,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
         ctx->log_sorted[b].release();
     }
     ctx->seeded_states2.release(); ctx->next_packet2.release(); ctx->wave_cold_dev.release();
-    ctx->seed_chk[0].release(); ctx->seed_chk[1].release();
+    ctx->seed_chk[0].release(); ctx->seed_chk[1].release(); ctx->vp_scratch.release();
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
@@ -1154,6 +1154,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 wc.chunk_first = first; wc.chunk_count = count;
                 wc.seeds = ctx->seeds.as<uint32_t>();
                 wc.seed_checkpoint = ctx->seed_chk[b].as<uint32_t>();
+                if (vpk) HIP_TRY(ctx, ctx->vp_scratch.ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(mc::VpResult)));
+                wc.vp_scratch = ctx->vp_scratch.as<mc::VpResult>();
                 mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci;
                 HIP_TRY(ctx, hipMemcpyAsync(wc_dev, &wc, sizeof(mc::WaveCold), hipMemcpyHostToDevice, st));
                 mc::WaveHot hot{};
