@@ -123,11 +123,11 @@ struct TardisMcContext {
     mc::DeviceProblem problem_host{};
     long long chunk_packets = 16LL << 20;  // packets per seeded-state chunk (2496 B each) of the cooperative kernel
     // launch geometry
-    int variant = -1;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel; -1: automatic (2, but 1 with v-packets)
+    int variant = -1;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel; -1: automatic (2)
     int blocks_per_cu = 16;
     int debug_flags = 0;
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
-    long long log_capacity = 500000000LL;  // line-visit records per chunk of the wave kernel (48 B + 8 B each)
+    long long log_capacity = 1500000000LL;  // upper bound of the line-visit records per chunk of the wave kernel (48 B + 8 B each)
     // wave kernel: chunks alternate between two buffer sets / streams, so that seeding and the estimator passes of one
     // chunk overlap the propagation of its neighbours
     hipStream_t stream2 = nullptr;
@@ -137,6 +137,7 @@ struct TardisMcContext {
     int pipeline_chunks = 1;  // >1: split a propagate call of the wave kernel into chunks on two streams (measured: a loss -- every chunk pays the drain of its last packets)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
     double traces_per_packet = 0.0;  // measured by the last propagate (sizes the line-visit log of the next one)
+    double log_budget_per_packet = 128.0;  // log records reserved per packet
     unsigned long long *events_host = nullptr;  // pinned: {events counter of the last propagate, its packet count}
     hipEvent_t ev_events = nullptr;
     std::vector<mc::WaveCold> wave_cold_host;
@@ -950,9 +951,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // init_err lives on this stack frame
     // the cooperative kernel relies on a sorted line list (bucket index, monotone stopping predicate); anything else --
     // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
-    // automatic choice: the wave-owner kernel, except with v-packets, where the group kernel's volleys are (still) faster
-    const int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets <= 32) ? 1 : 2);
-    const bool cooperative = ctx->lines_sorted && (variant == 2 || (variant == 1 && (!vpk || c.number_of_vpackets <= 32)));
+    // automatic choice: the wave-owner kernel (its pooled v-packet volleys take up to 32 v-packets per volley: one bit of
+    // the roulette predictor each; beyond that the lane-per-packet kernel)
+    const int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : 2);
+    const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2) && (!vpk || c.number_of_vpackets <= 32);
 
     if (!cooperative) {
         // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment
@@ -979,7 +981,17 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const long long want = (ctx->n_packets + ctx->pipeline_chunks - 1) / ctx->pipeline_chunks;
             chunk = std::min(chunk, std::max<long long>(1LL << 20, (want + 65535) / 65536 * 65536));
         }
-        const bool two_streams = wave_kernel && chunk < ctx->n_packets;
+        // the line-visit log of a chunk must fit log_capacity: 1.5x the traces per packet measured in the last iteration (128
+        // per packet before anything was measured), one region per wave; a region that overflows falls back to atomics
+        if (ctx->events_host && ctx->ev_events && hipEventQuery(ctx->ev_events) == hipSuccess && ctx->events_host[1] > 0)
+            ctx->traces_per_packet = (double)ctx->events_host[0] / (double)ctx->events_host[1];
+        // (the budget only ever grows, and only when the measured need comes within 20 % of it: resizing a 30 GB log costs more
+        // than an iteration)
+        if (1.2 * ctx->traces_per_packet > ctx->log_budget_per_packet) ctx->log_budget_per_packet = 1.5 * ctx->traces_per_packet;
+        const double log_per_packet = ctx->log_budget_per_packet;
+        if (wave_kernel && ctx->log_capacity > 0)
+            chunk = std::max<long long>(1 << 16, std::min<long long>(chunk, (long long)((double)ctx->log_capacity / log_per_packet)));
+        const bool two_streams = wave_kernel && chunk < ctx->n_packets && ctx->pipeline_chunks > 1;
         if (two_streams && !ctx->stream2) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1047,13 +1059,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         if (wave_kernel) {
             const int tiles = (ctx->n_lines + mc::EST_TILE - 1) / mc::EST_TILE;
             n_bins = ctx->n_shells * std::max(tiles, 1);
-            // the log must hold the traces of one chunk, in one region per wave: 2x the measured traces per packet of the last
-            // iteration (96 per packet before anything was measured); a region that overflows falls back to atomics
-            if (ctx->events_host && ctx->ev_events && hipEventQuery(ctx->ev_events) == hipSuccess && ctx->events_host[1] > 0)
-                ctx->traces_per_packet = (double)ctx->events_host[0] / (double)ctx->events_host[1];
-            const double per_packet = ctx->traces_per_packet > 0 ? std::max(16.0, 2.0 * ctx->traces_per_packet) : 128.0;
             unsigned long long cap = std::min<unsigned long long>((unsigned long long)ctx->log_capacity,
-                                                                  (unsigned long long)((double)chunk * per_packet) + 65536ull);
+                                                                  (unsigned long long)((double)chunk * log_per_packet) + 65536ull);
             if (n_bins > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernels add their terms directly
             cap = std::min<unsigned long long>(cap, 0xfffffff0ull);
             for (int b = 0; b < (two_streams ? 2 : 1); ++b) {
