@@ -1092,6 +1092,12 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             hipError_t e = hipMemsetAsync(bin_count, 0, (size_t)(n_bins + 1) * sizeof(unsigned), st);
             if (e != hipSuccess) return e;
             const size_t hist_lds = (size_t)n_bins * sizeof(unsigned);
+            if (hist_lds > 64 * 1024) {  // more than the default dynamic-LDS limit: BASELINE config 5 has 100 shells x 245 tiles
+                e = hipFuncSetAttribute((const void *)mc::bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
+                if (e != hipSuccess) return e;
+                e = hipFuncSetAttribute((const void *)mc::bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
+                if (e != hipSuccess) return e;
+            }
             const int bin_blocks = cus * 4;
             hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.region_count, lg.n_regions,
                                lg.region_capacity, n_bins, bin_count);

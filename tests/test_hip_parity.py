@@ -396,3 +396,28 @@ def test_chunked_two_stream_pipeline_matches(oracle):
     assert np.array_equal(a.output_nus, b.output_nus) and np.array_equal(a.output_energies, b.output_energies)
     assert_allclose(a.j_blue_estimator, b.j_blue_estimator, rtol=EST_RTOL)
     assert a.counters["events"] == b.counters["events"]
+
+
+@pytest.mark.gpu
+def test_config5_shape_small(oracle):
+    """BASELINE configs[4] shape (100 shells, 5e5 lines, macroatom, 10 v-packets) at a packet count the oracle finishes in
+    seconds: the largest table sizes of the baseline (24 500 estimator tiles, 144-KiB binning histograms)."""
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=23, n_packets=3_000, n_shells=100, n_lines=500_000, line_interaction_type="macroatom",
+                                  n_vpackets=10)
+    ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
+    eng = Engine(0)
+    eng.set_geometry(prob.geometry, prob.time_explosion)
+    eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+    eng.set_packets(prob.packet_collection)
+    eng.reset_estimators(); eng.propagate(); eng.synchronize()
+    got = eng.get_results(track_last_interaction=True)
+    eng.close()
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    assert_allclose(got.j_estimator, ref.j_estimator, rtol=EST_RTOL)
+    assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+    assert_allclose(got.edotlu_estimator, ref.edotlu_estimator, rtol=EST_RTOL)
+    assert_allclose(got.v_packets_energy_hist, ref.v_packets_energy_hist, rtol=EST_RTOL)
+    for k in ("line_visits", "events", "macro_transitions", "vpacket_line_visits", "vpackets", "rng_draws"):
+        assert got.counters[k] == ref.counters[k], k
