@@ -106,6 +106,10 @@ struct GroupArgs {
     // line activates; trans_rec[t] = {emission line id, transition type, first, end transition of the destination level}
     const int2 *line_block;
     const int4 *trans_rec;
+    // wave kernel: cum_t[s][t] = the reference's running sum of the transition probabilities from the start of t's block
+    // up to and including t (same additions in the same order, so the jump search compares the very numbers the
+    // reference's loop does); trans_nu[t] = nu of the line transition t emits (0 for internal transitions)
+    const double *cum_t, *trans_nu;
     double *jblue_t, *edot_t;
     long long est_copy_stride;
     unsigned long long *next_packet;

@@ -57,7 +57,7 @@ template <bool FULL, bool VPK>
 __host__ __device__ constexpr size_t wave_kernel_lds_bytes(int n_shells)
 {
     return sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0) + (size_t)(VPK ? WV_RING_VPK : WV_RING) * 64 * sizeof(double) +
-           (size_t)(VPK ? 5 : 2) * (size_t)n_shells * sizeof(double);  // J, nu_bar (+ r_inner, r_outer, n_e for the v-packets)
+           (size_t)5 * (size_t)n_shells * sizeof(double);  // J, nu_bar, r_inner, r_outer, n_e
 }
 
 // result of one (possibly speculative) v-packet trace, handed from the worker lane to the owner lane through global scratch
@@ -74,6 +74,7 @@ struct WaveHot {
     const double *nu_line, *tau_t;
     int n_lines, n_shells, disable_line_scattering, debug_flags;
     double t_exp, tc, rcp_tc;
+    int ls_min_active, ls_max_steps;  // lane sweep: leave the sweep phase once this few lanes are still sweeping / after this many steps
 };
 struct WaveCold {
     GroupArgs P;
@@ -167,6 +168,69 @@ __device__ __forceinline__ void sweep_step(const WaveHot &P, SweepSlot &s, const
         }
         s.owner = -1;
     }
+}
+
+
+// ---- lane sweep (LS instantiations, partial relativity): every lane sweeps the line list of ITS packet, eight lines per step.
+//
+// The reference's per-line work (distance to the line, three-way minimum, optical-depth test) only matters at the line
+// where the trace stops; for all lines before it, it is enough to PROVE that the reference's tests come out negative.
+// With X = comov_nu - nu_line >= 0, K' >= chi C t / nu (rounded up by 2^-40 relative) and x = RN(K' X):
+//     RN(chi d_trace) <= x                       (d_trace = RN(RN(RN(X / nu) C) t) <= (X C t / nu)(1 + 3u), or 0 for a close line)
+//     X  <  X_b = (d_boundary nu / (C t))(1 - 2^-40)   =>  d_trace < d_boundary
+//     x  <  RN(tau_event - tau_prev)             =>  d_trace < d_continuum = RN(RN(tau_event - tau_prev) / chi)
+//     RN(tau_incl + x) <= tau_event              =>  !(tau_combined > tau_event)          (rounding is monotone)
+// so the line cannot stop the trace and only tau_incl = tau_prev + tau_line (the reference's serial sum) is carried on:
+// 5 flops and 4 compares per line instead of two divisions and the full predicate.  The first line that fails one of the
+// bounds (and the last line of the list, and every line of a trace whose operands are outside mid_range) is evaluated
+// with the reference's own arithmetic by lane_exact_line() at the start of the lane's next step.
+__device__ __forceinline__ int lane_exact_line(const WaveHot &P, int line, double nu_line, double tau_line, double tau_prev, double nu,
+                                               double comov_nu, double chi, double tau_event, double d_boundary, double &distance)
+{   // trace_packet's loop body for one line (modes/homologous_rad_packet_transport.py:100-156), as in sweep_step(); the two
+    // quotients are plain divisions here (exact_div<true> returns the same correctly rounded values)
+    const double tau_incl = tau_prev + tau_line;
+    const double d_cont = (tau_event - tau_prev) / chi;
+    const bool is_last = line == P.n_lines - 1;
+    const double nu_diff = comov_nu - nu_line;
+    const double q = nu_diff / nu;
+    const bool close = fabs(q) < CLOSE_LINE_THRESHOLD;
+    const bool err = !is_last && !close && !(nu_diff >= 0);
+    const double d_far = q * C_LIGHT * P.t_exp;
+    const double d_trace = is_last ? MISS_DISTANCE : (close ? 0.0 : d_far);
+    const double tau_combined = tau_incl + chi * d_trace;
+    double dmin = d_trace;
+    if (d_boundary < dmin) dmin = d_boundary;
+    if (d_cont < dmin) dmin = d_cont;
+    const bool stop_b = !err && d_trace != 0 && dmin == d_boundary;
+    const bool stop_e = !err && d_trace != 0 && !stop_b && dmin == d_cont;
+    const bool stop_l = !err && !stop_b && !stop_e && tau_combined > tau_event && !P.disable_line_scattering;
+    distance = stop_b ? d_boundary : (stop_e ? d_cont : d_trace);
+    return stop_b ? 1 : (stop_e ? 2 : (stop_l ? 3 : (err ? 4 : 0)));
+}
+constexpr int LS_CHUNK = 8;  // lines per lane and step (the line list and the tau table carry this much slack at the end)
+
+// Running sums of the transition probabilities, block by block (macro_atom.py:87-97: `probability += transition_probabilities[i, shell]`
+// from block_start): one thread per (block, shell) repeats the reference's additions once per opacity state, so that a
+// jump becomes a search for the first running sum that exceeds the drawn number.  `negative` is raised if a probability is
+// negative (the sums would not be monotone; the host then keeps such problems off the searching kernel).
+__global__ void __launch_bounds__(256) macro_cumulative_kernel(const double *__restrict__ prob_t, double *__restrict__ cum_t,
+                                                                const int *__restrict__ block_edge, int n_blocks, long long n_trans,
+                                                                int n_shells, int *negative)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n_blocks * n_shells) return;
+    const int b = (int)(i % n_blocks), s = (int)(i / n_blocks);
+    const double *p = prob_t + (long long)s * n_trans;
+    double *c = cum_t + (long long)s * n_trans;
+    double carry = 0.0;
+    bool neg = false;
+    for (int k = block_edge[b]; k < block_edge[b + 1]; ++k) {
+        const double v = p[k];
+        neg |= !(v >= 0.0);
+        carry += v;
+        c[k] = carry;
+    }
+    if (neg) atomicOr(negative, 1);
 }
 
 // init_genrand up to word 397, one packet per lane: the only part of the start state that is ever precomputed in the lazy mode
@@ -322,7 +386,7 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
     return status == ST_EMITTED ? 1 : 0;
 }
 
-template <bool FULL, bool TRACK, int G, bool VPK>
+template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3 : 4, VPK ? 3 : 4))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -332,11 +396,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     double *ring = reinterpret_cast<double *>(lds_raw + sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0));  // [RING][64]
     double *lds_J = ring + RING * 64;
     double *lds_nubar = lds_J + H.n_shells;
-    double *lds_geo = lds_nubar + H.n_shells;  // VPK only: r_inner | r_outer | n_e
-    if (VPK) {
-        for (int s = threadIdx.x; s < H.n_shells; s += 64) {
-            lds_geo[s] = W->P.r_inner[s]; lds_geo[H.n_shells + s] = W->P.r_outer[s]; lds_geo[2 * H.n_shells + s] = W->P.n_e[s];
-        }
+    double *lds_geo = lds_nubar + H.n_shells;  // r_inner | r_outer | n_e
+    for (int s = threadIdx.x; s < H.n_shells; s += 64) {
+        lds_geo[s] = W->P.r_inner[s]; lds_geo[H.n_shells + s] = W->P.r_outer[s]; lds_geo[2 * H.n_shells + s] = W->P.n_e[s];
     }
     const int lane = threadIdx.x;  // one wave per workgroup
     for (int s = lane; s < 2 * H.n_shells; s += 64) lds_J[s] = 0.0;
@@ -370,6 +432,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     unsigned log_used = 0;  // wave-uniform: records this wave has appended to its log region
     unsigned long long visits = 0;
     unsigned dbg_rounds = 0;  // wave-uniform profiling counter: sweep rounds (reported through counters[7])
+    // lane sweep (LS): the trace this lane is sweeping (it may span several passes of the event loop).  What only the exact
+    // evaluation of a line needs is parked in LDS: chi in sh.d_cont0, the boundary distance in sh.d_boundary (where the
+    // result goes, too); the packet's nu and Doppler factor are the owner's p.nu and dop.
+    bool s_active = false, s_exact = false, s_fast = false;
+    int s_line = 0;
+    unsigned s_row = 0;
+    double s_tau = 0.0, s_tau_event = 0.0, s_kp = 0.0, s_xb = 0.0;
 
     auto draw = [&]() {
         const double v = ring[r_head * 64 + lane];
@@ -432,8 +501,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         r_gpos = (k0 + 8 == MT_N) ? 0x10000 : r_gpos + 8;  // bit 16: the state has been regenerated once
     };
 
+    unsigned dbg_passes = 0;
+#ifdef TMC_SECTION_TIMERS  // profiling builds only: wall time of the sections of a pass, section (debug_flags >> 8) & 7 -> counters[7]
+    unsigned long long sec_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long sec_prev = __builtin_amdgcn_s_memtime();
+#define TMC_SEC(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sec_t[i] += now_ - sec_prev; sec_prev = now_; }
+#else
+#define TMC_SEC(i)
+#endif
     for (;;) {
         // ============================================================ event phase (lane-per-packet)
+        ++dbg_passes;
         asm volatile("" ::: "memory");  // the cold arguments are (re)loaded here, once per pass
         const GroupArgs &P = W->P;
         const EstimatorLog &log = W->log;
@@ -441,7 +519,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         const long long chunk_first = W->chunk_first, chunk_count = W->chunk_count;
         double *const jb = P.jblue_t, *const ed = P.edot_t;
         // every live packet gets the draws of one pass: new direction, first macro-atom jump, next tau_event
-        const bool ready = state == WS_SWEEP;  // every prepared trace has been swept
+        const bool ready = state == WS_SWEEP && !(LS && s_active);  // the prepared trace has been swept
         refill(__ballot((ready || state == WS_NEED_TRACE) && r_cnt < 3), seeded_states);
         int err = 0, type = 0, emit = -1, mb0 = 0, mb1 = 0;
         double inv_new = 1.0, distance = 0.0;
@@ -490,6 +568,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 }
             }
         }
+        TMC_SEC(0)
         // ---- epilogue of the finished traces: move, estimators, boundary / scattering
         if (ready && !err) {
             // move_r_packet + update_estimators_bulk (packets/movement.py:31-76)
@@ -537,9 +616,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 }
             }
         }
-        // ---- macro_atom_interaction (macro_atom.py:52-104), one jump of every walking packet per pass
-        if (P.line_interaction_type == 2) {
-            // macroatom mode (long jump chains over big transition tables): the wave's G-lane groups scan the blocks, G
+        TMC_SEC(1)
+        // ---- macro_atom_interaction (macro_atom.py:52-104): one jump of every walking packet per round.  The reference adds
+        // the block's probabilities up until the sum exceeds the drawn number; the sums are precomputed (cum_t, same
+        // additions in the same order), so the jump is the first entry of the block's monotone run that exceeds it:
+        // the first four entries in one round trip (the short blocks of downbranch end there), then a 4-ary search.
+        if (P.line_interaction_type == 2 && !(P.debug_flags & 128)) {  // (flag 128: the per-lane search below, for tests)
+            // macroatom mode (long chains of jumps, and a wave waits for its longest chain: one coalesced round trip per jump): the wave's G-lane groups scan the blocks, G
             // probabilities per coalesced load, accumulated in the reference's serial order (macro_atom_group() of the
             // group kernel).  The work items and results live in LDS that the trace parameters do not need right now.
             double *mac_event = sh.nu;
@@ -638,37 +721,64 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 }
             }
         }
-        // downbranch (one short block): the lane walks its block itself
-        while (__ballot(in_macro)) {
-            refill(__ballot(in_macro && r_cnt < 2), seeded_states);
-            if (in_macro) {
-                const unsigned row = (unsigned)p.shell * (unsigned)P.n_trans;
-                const double event = draw();
-                double carry = 0.0;
-                int k = mb0;
-                bool found = false;
-                for (; k < mb1; ++k) {
-                    carry += P.prob_t[row + (unsigned)k];
-                    if (carry > event) { found = true; break; }
-                }
-                if (!found) { macro += (unsigned)(mb1 - mb0); err = ERR_MACRO_ATOM; in_macro = false; }
-                else {
-                    macro += (unsigned)(k - mb0 + 1);
-                    const int4 rec = P.trans_rec[(unsigned)k];
-                    emit = rec.x; mb0 = rec.z; mb1 = rec.w;
-                    if (rec.y < 0) {
-                        in_macro = false;
-                        if (rec.y != -1) err = ERR_UNSUPPORTED;
+        // downbranch (one jump over a short block)
+        bool have_emit_nu = false;
+        double emit_nu = 0.0;
+        {
+            bool searching = false;  // the first four entries did not decide this lane's jump: 4-ary search in [lo, hi)
+            int lo = 0, hi = 0;      // cum[j] <= event for all block entries j < lo; hi == mb1 or cum[hi] > event
+            double event = 0.0;
+            while (__ballot(in_macro)) {
+                refill(__ballot(in_macro && !searching && r_cnt < 1), seeded_states);
+                if (in_macro) {
+                    const double *__restrict__ cum = P.cum_t + (unsigned)p.shell * (unsigned)P.n_trans;
+                    // one round trip per round for every walking lane, whichever stage it is in
+                    int i0, i1, i2, i3;
+                    if (!searching) {
+                        event = draw();
+                        const int last = mb1 - 1;
+                        i0 = max(min(mb0, last), 0); i1 = max(min(mb0 + 1, last), 0); i2 = max(min(mb0 + 2, last), 0); i3 = max(min(mb0 + 3, last), 0);
+                    } else {
+                        const int n = hi - lo;
+                        i0 = lo + (n >> 2); i1 = lo + (n >> 1); i2 = lo + ((3 * n) >> 2); i3 = i2;
+                    }
+                    const double a0 = cum[(unsigned)i0], a1 = cum[(unsigned)i1], a2 = cum[(unsigned)i2], a3 = cum[(unsigned)i3];
+                    int k = -2;  // >= 0: the jump goes to transition k; -1: no entry exceeds the number drawn; -2: search on
+                    if (!searching) {
+                        k = -1;
+                        if (mb0 + 3 < mb1 && a3 > event) k = mb0 + 3;
+                        if (mb0 + 2 < mb1 && a2 > event) k = mb0 + 2;
+                        if (mb0 + 1 < mb1 && a1 > event) k = mb0 + 1;
+                        if (mb0 < mb1 && a0 > event) k = mb0;
+                        if (k < 0 && mb1 - mb0 > 4) { searching = true; lo = mb0 + 4; hi = mb1; k = -2; }
+                    } else {
+                        if (a0 > event) hi = i0;
+                        else if (a1 > event) { lo = i0 + 1; hi = i1; }
+                        else if (a2 > event) { lo = i1 + 1; hi = i2; }
+                        else lo = i2 + 1;
+                        if (lo >= hi) { searching = false; k = lo < mb1 ? lo : -1; }
+                    }
+                    if (k == -1) { macro += (unsigned)(mb1 - mb0); err = ERR_MACRO_ATOM; in_macro = false; }
+                    else if (k >= 0) {
+                        macro += (unsigned)(k - mb0 + 1);
+                        const int4 rec = P.trans_rec[(unsigned)k];
+                        emit_nu = P.trans_nu[(unsigned)k]; have_emit_nu = true;
+                        emit = rec.x; mb0 = rec.z; mb1 = rec.w;
+                        if (rec.y < 0) {
+                            in_macro = false;
+                            if (rec.y != -1) err = ERR_UNSUPPORTED;
+                        }
                     }
                 }
             }
         }
+        TMC_SEC(2)
         // ---- finish the interaction, hand finished packets over
         if (ready) {
             if (interacted && !err) {
                 int emit_id = -1;
                 if (type == IT_LINE) {  // line_emission (interaction_events.py:227-258); its inverse Doppler factor == inv_new
-                    p.nu = P.nu_line[emit] * inv_new;
+                    p.nu = (have_emit_nu ? emit_nu : P.nu_line[emit]) * inv_new;
                     p.next_line_id = emit + 1;
                     emit_id = emit;
                 }
@@ -717,6 +827,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 state = WS_NEED_PACKET;
             }
         }
+        TMC_SEC(3)
         // ---- fetch packets (one global atomic per wave and pass)
         {
             const unsigned long long need_pkt = __ballot(state == WS_NEED_PACKET);
@@ -950,6 +1061,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 state = WS_NEED_PACKET;
             }
         }
+        TMC_SEC(4)
         // ---- prologue of the next trace (trace_packet, modes/homologous_rad_packet_transport.py:30-98)
         refill(__ballot(state == WS_NEED_TRACE && r_cnt < 1), seeded_states);
         {
@@ -957,29 +1069,110 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             if (go) {
                 const double velocity = p.r / t;
                 dop = doppler_factor<FULL>(velocity, p.mu);
-                double chi_e = P.n_e[p.shell] * P.sigma_thomson;
+                double chi_e = lds_geo[2 * H.n_shells + p.shell] * P.sigma_thomson;
                 if (FULL) chi_e *= dop;
                 double d_boundary;
                 int delta;
-                distance_boundary(p.r, p.mu, P.r_inner[p.shell], P.r_outer[p.shell], d_boundary, delta);
+                distance_boundary(p.r, p.mu, lds_geo[p.shell], lds_geo[H.n_shells + p.shell], d_boundary, delta);
                 const double tau_event = -mcm::log(draw());
                 const double comov_nu = p.nu * dop;
                 ++events;
                 const bool fast = mid_range(p.nu) && mid_range(chi_e) && mid_range(tau_event) && mid_range(p.energy) &&
                                   mid_range(p.r) && mid_range(comov_nu) && mid_range(P.t_exp) && !(P.debug_flags & 4);
                 pflags = (fast ? 1 : 0) | ((delta + 1) << 1);
-                sh.nu[lane] = p.nu; sh.rcp_nu[lane] = 1.0 / p.nu; sh.comov_nu[lane] = comov_nu;
-                sh.chi[lane] = chi_e; sh.rcp_chi[lane] = 1.0 / chi_e;
-                sh.tau_event[lane] = tau_event; sh.d_boundary[lane] = d_boundary;
-                sh.d_cont0[lane] = tau_event / chi_e;  // distance_continuum in force at the first line
-                if (FULL) { shf.r[lane] = p.r; shf.mu[lane] = p.mu; }
-                sh.cursor[lane] = p.next_line_id;
-                sh.rowfast[lane] = (int)(((unsigned)p.shell * (unsigned)L) | (fast ? 0x80000000u : 0u));
+                if (LS) {
+                    sh.d_cont0[lane] = chi_e; sh.d_boundary[lane] = d_boundary;
+                    s_tau_event = tau_event;
+                    s_tau = 0.0; s_line = p.next_line_id; s_row = (unsigned)p.shell * (unsigned)L;
+                    s_kp = ((chi_e * H.tc) / p.nu) * (1.0 + 0x1p-40);
+                    s_xb = ((d_boundary * p.nu) * H.rcp_tc) * (1.0 - 0x1p-40);
+                    s_fast = fast && mid_range(s_kp);
+                    s_exact = !s_fast || s_line >= L - 1;
+                    s_active = true;
+                } else {
+                    sh.nu[lane] = p.nu; sh.rcp_nu[lane] = 1.0 / p.nu; sh.comov_nu[lane] = comov_nu;
+                    sh.chi[lane] = chi_e; sh.rcp_chi[lane] = 1.0 / chi_e;
+                    sh.tau_event[lane] = tau_event; sh.d_boundary[lane] = d_boundary;
+                    sh.d_cont0[lane] = tau_event / chi_e;  // distance_continuum in force at the first line
+                    if (FULL) { shf.r[lane] = p.r; shf.mu[lane] = p.mu; }
+                    sh.cursor[lane] = p.next_line_id;
+                    sh.rowfast[lane] = (int)(((unsigned)p.shell * (unsigned)L) | (fast ? 0x80000000u : 0u));
+                }
                 state = WS_SWEEP;
             }
-            const unsigned long long go_mask = __ballot(go);
-            if (go) sh.queue[(q_tail + __popcll(go_mask & ((1ull << lane) - 1ull))) & 63] = lane;
-            q_tail += __popcll(go_mask);
+            if (!LS) {
+                const unsigned long long go_mask = __ballot(go);
+                if (go) sh.queue[(q_tail + __popcll(go_mask & ((1ull << lane) - 1ull))) & 63] = lane;
+                q_tail += __popcll(go_mask);
+            }
+        }
+
+        TMC_SEC(5)
+        // ============================================================ sweep phase, lane sweep: every lane its own trace
+        if (LS) {
+            for (int step = 0;; ++step) {
+                const unsigned long long act = __ballot(s_active);
+                if (!act) break;
+                if (step > 0) {
+                    // Finished lanes wait for the event phase, which costs the same however few lanes take part in it: go
+                    // on sweeping until enough of the wave has something to do there.
+                    const unsigned long long waiting = __ballot(state == WS_SWEEP && !s_active);
+                    if (waiting && (__popcll(act) <= H.ls_min_active || step >= H.ls_max_steps)) break;
+                }
+                ++dbg_rounds;
+                if (s_active) {
+                    const double *__restrict__ pn = H.nu_line + (unsigned)s_line;
+                    const double *__restrict__ pt = H.tau_t + (s_row + (unsigned)s_line);
+                    double nl[LS_CHUNK], tl[LS_CHUNK];
+#pragma unroll
+                    for (int k = 0; k < LS_CHUNK; ++k) { nl[k] = pn[k]; tl[k] = pt[k]; }
+                    int adv = 0;  // lines of this chunk the trace has passed
+                    const double comov = p.nu * dop;
+                    if (s_exact) {
+                        s_exact = !s_fast;
+                        const double chi = sh.d_cont0[lane], d_bound = sh.d_boundary[lane];
+                        int code;
+                        double dist;
+                        if (s_line < L) {
+                            ++visits;
+                            code = lane_exact_line(H, s_line, nl[0], tl[0], s_tau, p.nu, comov, chi, s_tau_event, d_bound, dist);
+                            if (!code) { s_tau = s_tau + tl[0]; adv = 1; }
+                        } else {
+                            // for-else (lines 157-172): the line list is exhausted; next_line_id is left untouched (bit 3)
+                            const double d_cont = (s_tau_event - s_tau) / chi;
+                            const bool cont = d_cont < d_bound;
+                            dist = cont ? d_cont : d_bound;
+                            code = (cont ? 2 : 1) | 8;
+                        }
+                        if (code) {
+                            sh.d_boundary[lane] = dist; sh.res_info[lane] = code; sh.res_line[lane] = (code & 8) ? 0 : s_line;
+                            s_active = false;
+                        }
+                    }
+                    if (s_active && s_fast) {
+                        const int n_fast = L - 1 - s_line;  // lines of the chunk that are not the last line of the list
+                        bool alive = true;
+                        const int k0 = adv;
+#pragma unroll
+                        for (int k = 0; k < LS_CHUNK; ++k) {
+                            if (alive && (k > 0 || k0 == 0)) {
+                                const double X = comov - nl[k];
+                                const double x = s_kp * X;
+                                const double D = s_tau_event - s_tau;
+                                const double tau_n = s_tau + tl[k];
+                                const double sum = tau_n + x;
+                                const bool ok = k < n_fast && X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
+                                if (ok) { s_tau = tau_n; ++adv; } else alive = false;
+                            }
+                        }
+                        visits += (unsigned long long)(adv - k0);
+                        if (!alive) s_exact = true;
+                    }
+                    s_line += adv;
+                }
+            }
+            TMC_SEC(6)
+            continue;
         }
 
         // ============================================================ sweep phase (G-lane groups work off the queue)
@@ -1037,6 +1230,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 else sweep_step<FULL, G, false>(H, cur, j, sh, visits);
             }
         }
+        TMC_SEC(6)
     }
 
     if (lane == 0 && W->log.region_capacity > 0) W->log.region_count[blockIdx.x] = min(log_used, W->log.region_capacity);
@@ -1046,7 +1240,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         if (lds_nubar[s] != 0.0) atomic_add_f64(&C->nubar[s], lds_nubar[s]);
     }
     // counters: wave-reduce, one atomic each
-    unsigned long long v = (j == 0) ? visits : 0ull;  // group-uniform: count once per group
+    unsigned long long v = (LS || j == 0) ? visits : 0ull;  // group sweeps: group-uniform, count once per group
     unsigned long long e = events, m = macro, d = draws, vv = vvisits_total, vc = vcount, vt = vtraced_total;
     for (int off = 32; off > 0; off >>= 1) {
         v += __shfl_down(v, off); e += __shfl_down(e, off); m += __shfl_down(m, off); d += __shfl_down(d, off);
@@ -1059,6 +1253,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         atomicAdd(&C->counters[5], d);
         if (VPK) { atomicAdd(&C->counters[3], vv); atomicAdd(&C->counters[4], vc); atomicAdd(&C->counters[7], vt); }
         if (H.debug_flags & 16) atomicAdd(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
+        if (H.debug_flags & 32) atomicAdd(&C->counters[7], (unsigned long long)dbg_passes);
+#ifdef TMC_SECTION_TIMERS
+        if (H.debug_flags & 64) {
+            unsigned long long tsel = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (((H.debug_flags >> 8) & 7) == i) tsel = sec_t[i];
+            atomicAdd(&C->counters[7], tsel);
+        }
+#endif
     }
 }
 

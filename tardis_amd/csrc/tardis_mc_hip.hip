@@ -97,7 +97,7 @@ struct TardisMcContext {
     DevBuf r_inner, r_outer;
     // opacity
     int n_lines = 0, n_trans = 0, n_levels = 0;
-    DevBuf nu_line, tau_t, n_e, prob_t, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec, bucket_first;
+    DevBuf nu_line, tau_t, n_e, prob_t, cum_t, trans_nu, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec, bucket_first;
     int bucket_shift = 0, bucket_n = 0;
     long long bucket_kmin = 0;
     bool lines_sorted = true;  // line_list_nu strictly usable by the index-based kernels (non-increasing, positive)
@@ -123,7 +123,9 @@ struct TardisMcContext {
     mc::DeviceProblem problem_host{};
     long long chunk_packets = 16LL << 20;  // packets per seeded-state chunk (2496 B each) of the cooperative kernel
     // launch geometry
-    int variant = -1;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel; -1: automatic (2)
+    int variant = -1;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel, group sweeps; 3: wave-owner kernel, lane sweeps; -1: automatic
+    bool prob_negative = false;  // a negative transition probability: the running sums are not monotone, no jump search
+    int ls_min_active = 32, ls_max_steps = 64;  // lane sweeps: when to leave the sweep phase (propagate_wave.hpp)
     int blocks_per_cu = 16;
     int debug_flags = 0;
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
@@ -503,7 +505,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
-    DevBuf *all[] = {&ctx->r_inner, &ctx->r_outer, &ctx->nu_line, &ctx->tau_t, &ctx->n_e, &ctx->prob_t, &ctx->line2level,
+    DevBuf *all[] = {&ctx->r_inner, &ctx->r_outer, &ctx->nu_line, &ctx->tau_t, &ctx->n_e, &ctx->prob_t, &ctx->cum_t, &ctx->trans_nu, &ctx->line2level,
                      &ctx->block_edge, &ctx->ttype, &ctx->dest, &ctx->tline, &ctx->staging, &ctx->line_block, &ctx->trans_rec, &ctx->bucket_first, &ctx->est, &ctx->grid, &ctx->r0,
                      &ctx->mu0, &ctx->nu0, &ctx->e0, &ctx->seeds, &ctx->out_nu, &ctx->out_e, &ctx->vlog_count,
                      &ctx->vlog_packet, &ctx->vlog_seq, &ctx->vlog_nu, &ctx->vlog_energy, &ctx->vlog_mu, &ctx->vlog_r,
@@ -542,6 +544,8 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vpacket_log_capacity") ctx->vlog_capacity = value;
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
+    else if (n == "lane_sweep_min_active") ctx->ls_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
+    else if (n == "lane_sweep_max_steps") ctx->ls_max_steps = (int)std::max<long long>(1, value);
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
     else if (n == "pipeline_chunks") ctx->pipeline_chunks = std::max(1, (int)value);
     else if (n == "log_capacity") ctx->log_capacity = std::max<long long>(0, value);
@@ -597,11 +601,13 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         }
     }
     int rc;
+    // (slack at the end of the line list and of the tau table: the lane sweep loads whole chunks, propagate_wave.hpp)
+    HIP_TRY(ctx, ctx->nu_line.ensure((L + 2 * mc::LS_CHUNK) * sizeof(double)));
     if ((rc = upload(ctx, ctx->nu_line, o->line_list_nu, L))) return rc;
     if ((rc = upload(ctx, ctx->n_e, o->electron_density, S))) return rc;
     // tau [L,S] -> [S][L]
     HIP_TRY(ctx, ctx->staging.ensure(std::max(L, T) * S * sizeof(double)));
-    HIP_TRY(ctx, ctx->tau_t.ensure(L * S * sizeof(double)));
+    HIP_TRY(ctx, ctx->tau_t.ensure((L * S + 2 * mc::LS_CHUNK) * sizeof(double)));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->staging.p, o->tau_sobolev, L * S * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->staging.as<double>(), ctx->tau_t.as<double>(), (long long)L, (long long)S));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -638,7 +644,33 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         }
         if ((rc = upload(ctx, ctx->line_block, lb.data(), lb.size()))) return rc;
         if ((rc = upload(ctx, ctx->trans_rec, rec.data(), rec.size()))) return rc;
+        // frequency of the line every emission transition ends in, next to its record (one round trip instead of two)
+        std::vector<double> tnu(macro ? T : 1, 0.0);
+        if (macro)
+            for (size_t t = 0; t < T; ++t)
+                if (o->transition_type[t] == -1) tnu[t] = o->line_list_nu[o->transition_line_id[t]];
+        if ((rc = upload(ctx, ctx->trans_nu, tnu.data(), tnu.size()))) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    {   // running sums of the transition probabilities within their blocks (macro_cumulative_kernel)
+        HIP_TRY(ctx, ctx->cum_t.ensure(T * S * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->cum_t.p, ctx->prob_t.p, T * S * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->prob_negative = false;
+        if (macro && E > 1) {
+            int *flag = nullptr;
+            HIP_TRY(ctx, hipMalloc((void **)&flag, sizeof(int)));
+            HIP_TRY(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+            const long long n = (long long)(E - 1) * (long long)S;
+            hipLaunchKernelGGL(mc::macro_cumulative_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prob_t.as<double>(),
+                               ctx->cum_t.as<double>(), ctx->block_edge.as<int>(), (int)(E - 1), (long long)T, (int)S, flag);
+            int neg = 0;
+            hipError_t e1 = hipGetLastError();
+            hipError_t e2 = hipMemcpyAsync(&neg, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+            hipError_t e3 = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(flag);
+            HIP_TRY(ctx, e1); HIP_TRY(ctx, e2); HIP_TRY(ctx, e3);
+            ctx->prob_negative = neg != 0;
+        }
     }
     ctx->lines_sorted = true;
     for (size_t i = 0; i < L; ++i)
@@ -953,8 +985,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
     // automatic choice: the wave-owner kernel (its pooled v-packet volleys take up to 32 v-packets per volley: one bit of
     // the roulette predictor each; beyond that the lane-per-packet kernel)
-    const int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : 2);
-    const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2) && (!vpk || c.number_of_vpackets <= 32);
+    int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : 2);
+    if (ctx->prob_negative && (variant == 2 || variant == 3)) variant = 1;  // (the wave kernel searches the monotone running sums)
+    const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2 || variant == 3) && (!vpk || c.number_of_vpackets <= 32);
 
     if (!cooperative) {
         // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment
@@ -975,7 +1008,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         // variant 1: cooperative kernel; MT19937 states are seeded per chunk by a lane-per-packet kernel
         long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
         // wave-owner kernel (lane-per-packet event code and v-packet volleys, groups as sweep and macro-atom workers)
-        const bool wave_kernel = variant == 2;
+        const bool wave_kernel = variant == 2 || variant == 3;
         if (wave_kernel && ctx->pipeline_chunks > 1 && ctx->n_packets >= (2LL << 20)) {
             // pipeline: ~pipeline_chunks chunks of at least 1 Mi packets, alternating between two streams
             const long long want = (ctx->n_packets + ctx->pipeline_chunks - 1) / ctx->pipeline_chunks;
@@ -1017,6 +1050,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells * n_lines exceeds the 32-bit table offsets of the cooperative kernel");
         P.r_inner = F.r_inner; P.r_outer = F.r_outer; P.nu_line = F.nu_line; P.tau_t = F.tau_t; P.n_e = F.n_e; P.prob_t = F.prob_t;
         P.line_block = ctx->line_block.as<int2>(); P.trans_rec = ctx->trans_rec.as<int4>();
+        P.cum_t = ctx->cum_t.as<double>(); P.trans_nu = ctx->trans_nu.as<double>();
         P.jblue_t = F.jblue_t; P.edot_t = F.edot_t; P.est_copy_stride = F.est_copy_stride;
         P.next_packet = F.next_packet;
         P.n_vpackets = F.n_vpackets; P.survival_probability = F.survival_probability; P.tau_russian = F.tau_russian;
@@ -1047,9 +1081,13 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 #define TMC_PICKW2(G_, V_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_, V_> : mc::propagate_wave_kernel<true, false, G_, V_>) \
                                  : (trk ? mc::propagate_wave_kernel<false, true, G_, V_> : mc::propagate_wave_kernel<false, false, G_, V_>))
 #define TMC_PICKW(G_) (vpk ? TMC_PICKW2(G_, true) : TMC_PICKW2(G_, false))
+#define TMC_PICKLS(G_, V_) (trk ? mc::propagate_wave_kernel<false, true, G_, V_, true> : mc::propagate_wave_kernel<false, false, G_, V_, true>)
         // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel)
         const int GW = ctx->group_size ? ctx->group_size : (ctx->n_lines <= 100000 ? 8 : 16);
-        if (wave_kernel) kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
+        const bool lane_sweep = variant == 3 && !full;  // (the bounds of the lane sweep are those of partial relativity)
+        if (wave_kernel && lane_sweep) kw = (GW == 16) ? (vpk ? TMC_PICKLS(16, true) : TMC_PICKLS(16, false)) : (vpk ? TMC_PICKLS(8, true) : TMC_PICKLS(8, false));
+        else if (wave_kernel) kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
+#undef TMC_PICKLS
 #undef TMC_PICKW2
 #undef TMC_PICKW
         // estimator log of the wave kernel (estimator_log.hpp)
@@ -1175,6 +1213,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
                 hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
                 hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
+                hot.ls_min_active = ctx->ls_min_active; hot.ls_max_steps = ctx->ls_max_steps;
                 hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));

@@ -98,7 +98,7 @@ def test_hip_matches_oracle_and_reference_on_golden_cases(engine, oracle, name):
     _check_golden_case(engine, oracle, name)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", [n for n in _golden.CASES if "_nv2" in n or "_nv3" in n])
 def test_every_kernel_variant_on_vpacket_golden_cases(engine, oracle, name, variant):
     """The automatic choice sends v-packet problems to the group kernel; the wave-owner kernel's lane-per-packet volleys and
@@ -344,6 +344,8 @@ def test_device_packet_spectrum_matches_numpy(engine):
     {"variant": 2, "log_capacity": 4096},           # line-visit log far too small: most traces take the direct-atomics path
     {"variant": 2, "log_capacity": 0},              # no log at all
     {"variant": 2, "waves_per_simd": 2},
+    {"variant": 3}, {"variant": 3, "lane_sweep_min_active": 0}, {"variant": 3, "lane_sweep_min_active": 63, "lane_sweep_max_steps": 1},
+    {"variant": 3, "log_capacity": 0},
 ], ids=lambda o: "-".join(f"{k}{v}" for k, v in o.items()))
 @pytest.mark.parametrize("mode", ["downbranch", "macroatom"])
 def test_kernel_variants_and_options_agree_with_the_oracle(oracle, options, mode):
