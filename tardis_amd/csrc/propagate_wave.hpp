@@ -33,6 +33,7 @@ constexpr int WV_RING = 8, WV_RING_VPK = 16;  // look-ahead doubles per packet (
                             // refills was measured: fewer refill rounds, but the extra 4 KiB of LDS costs the 12th wave of the CU
 enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3 };
 constexpr int RES_PENDING = -1;
+constexpr int WV_RESERVE = 32;  // packets a wave reserves per atomic on the chunk's packet counter
 
 // per-wave LDS, structure of arrays indexed by lane
 struct WaveShared {
@@ -45,12 +46,6 @@ struct WaveShared {
 };
 struct WaveSharedFull {  // only read by the full-relativity sweep
     double r[64], mu[64];
-};
-// Last-interaction tracker (packets/trackers/tracker_last_interaction.py:8-254), kept in the owner lane's registers;
-// nu/energy/after_nu/after_energy are the packet's final nu and energy.
-struct LaneTracker {
-    double radius, before_nu, before_mu, before_energy, after_mu;
-    int shell_id, line_absorb_id, line_emit_id, interaction_type;
 };
 
 template <bool FULL, bool VPK>
@@ -74,17 +69,20 @@ struct WaveHot {
     const double *nu_line, *tau_t;
     int n_lines, n_shells, disable_line_scattering, debug_flags;
     double t_exp, tc, rcp_tc;
+    const int2 *line_block;           // lane sweep: macro-atom block of a line (null unless line_interaction_type != 0), requested as soon as a line stops the trace
     int ls_min_active, ls_max_steps;  // lane sweep: leave the sweep phase once this few lanes are still sweeping / after this many steps
 };
+struct LaunchRec;
 struct WaveCold {
     GroupArgs P;
+    // A copy of the full problem description, NOT read through P.cold: loads through a pointer that was itself loaded from
+    // memory cannot use the scalar cache (the kernel's own stores might alias them), so every `cold->field` access would be
+    // a vector-memory round trip in the middle of the event phase; `W` is a restrict-qualified kernel argument.
+    DeviceProblem D;
     EstimatorLog log;
     uint32_t *seeded_states;
     long long chunk_first, chunk_count;
-    const uint32_t *seeds;
-    // lazy seeding: only word 397 of every packet's init_genrand sequence is precomputed (seed_checkpoint_kernel); the two
-    // windows of initial words a regeneration step needs are continued from mt[k] and mt[k+397] inside the refill
-    const uint32_t *seed_checkpoint;
+    const LaunchRec *launch;  // [chunk_count] prepared packets (launch_prep_kernel)
     VpResult *vp_scratch;  // [waves][64 * VP_ROUND]
 };
 
@@ -233,15 +231,66 @@ __global__ void __launch_bounds__(256) macro_cumulative_kernel(const double *__r
     if (neg) atomicOr(negative, 1);
 }
 
-// init_genrand up to word 397, one packet per lane: the only part of the start state that is ever precomputed in the lazy mode
-__global__ void __launch_bounds__(256) seed_checkpoint_kernel(const uint32_t *__restrict__ seeds, uint32_t *__restrict__ checkpoint,
-                                                              long long first, long long count)
+// What a lane needs to start a packet, prepared by launch_prep_kernel for the whole chunk (one record per packet, 48 bytes): the
+// packet in the lab frame (set_packet_props_{partial,full}_relativity, classic/packet_propagation.py:254-318), its first line
+// (initialize_line_id, packets/radiative_packet.py:96-110), its seed and word 397 of its init_genrand sequence (the only
+// part of the MT19937 start state that is ever precomputed, see refill()).  Fetching a packet is then one round trip
+// instead of a chain of four (inputs, bucket index, line scan).
+struct __attribute__((aligned(16))) LaunchRec {
+    double r, mu, nu, energy;
+    uint32_t seed, checkpoint;
+    int line0, pad;
+};
+struct LaunchPrepArgs {
+    const double *r0, *mu0, *nu0, *e0, *nu_line;
+    const uint32_t *seeds;
+    const int *bucket_first;
+    int bucket_shift, bucket_n, n_lines;
+    long long bucket_kmin;
+    double t_exp;
+    LaunchRec *out;
+    long long first, count;
+};
+template <bool FULL>
+__global__ void __launch_bounds__(256) launch_prep_kernel(LaunchPrepArgs a)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    uint32_t x = seeds[first + i];
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.count) return;
+    const long long i = a.first + j;
+    LaunchRec rec;
+    rec.seed = a.seeds[i];
+    uint32_t x = rec.seed;
     for (int k = 1; k <= 397; ++k) x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
-    checkpoint[i] = x;
+    rec.checkpoint = x;
+    double r = a.r0[i], mu = a.mu0[i], nu = a.nu0[i], energy = a.e0[i];
+    const double t = a.t_exp;
+    {
+        const double velocity = r / t;
+        const double inv = inverse_doppler_factor<FULL>(velocity, mu);
+        if (FULL) {
+            const double beta = velocity / C_LIGHT;
+            nu *= inv; energy *= inv;
+            mu = (mu + beta) / (1 + beta * mu);
+        } else { nu *= inv; energy *= inv; }
+    }
+    const int L = a.n_lines;
+    {
+        const double velocity = r / t;
+        const double comov_nu = nu * doppler_factor<FULL>(velocity, mu);
+        int lo;
+        const long long kk = (long long)((unsigned long long)__double_as_longlong(comov_nu > 0.0 ? comov_nu : 0.0) >> a.bucket_shift) - a.bucket_kmin;
+        if (kk >= a.bucket_n) lo = 0;
+        else if (kk < 0) lo = L;
+        else {
+            lo = a.bucket_first[kk];
+            const int hi = kk > 0 ? a.bucket_first[kk - 1] : L;
+            while (lo < hi && a.nu_line[(unsigned)lo] >= comov_nu) ++lo;
+        }
+        if (lo == L) lo -= 1;
+        rec.line0 = lo;
+    }
+    rec.r = r; rec.mu = mu; rec.nu = nu; rec.energy = energy; rec.pad = 0;
+    a.out[j] = rec;
 }
 
 // ---- v-packets (packets/virtual_packet.py:82-386), lane-per-packet: every lane traces the v-packets of ITS packet one after
@@ -423,11 +472,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     unsigned pred_bits = 0;  // roulette predictor of the volleys: bit i = v-packet i of the last volley took a roulette draw
     unsigned long long vtraced_total = 0;
     int trk_count = 0, trk_boundary = 0;  // interactions_count, boundary crossings since the last interaction
-    LaneTracker trk;
-    trk.radius = trk.before_nu = trk.before_mu = trk.before_energy = trk.after_mu = 0.0;
-    trk.shell_id = trk.line_absorb_id = trk.line_emit_id = trk.interaction_type = -1;
     bool trk_any = false;
-    bool exhausted = false;  // wave-uniform: the chunk has no more packets
+    bool exhausted = false;  // wave-uniform: the chunk has no more packets to reserve
+    long long res_next = 0, res_end = 0;  // wave-uniform: the block of packets this wave has reserved and not yet started
     int q_head = 0, q_tail = 0;  // wave-uniform: queue of prepared traces
     unsigned log_used = 0;  // wave-uniform: records this wave has appended to its log region
     unsigned long long visits = 0;
@@ -435,10 +482,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     // lane sweep (LS): the trace this lane is sweeping (it may span several passes of the event loop).  What only the exact
     // evaluation of a line needs is parked in LDS: chi in sh.d_cont0, the boundary distance in sh.d_boundary (where the
     // result goes, too); the packet's nu and Doppler factor are the owner's p.nu and dop.
-    bool s_active = false, s_exact = false, s_fast = false;
+    bool s_active = false, s_fast = false;
     int s_line = 0;
     unsigned s_row = 0;
     double s_tau = 0.0, s_tau_event = 0.0, s_kp = 0.0, s_xb = 0.0;
+    int2 pre_blk = make_int2(0, 0);  // line_block[] of the line that stopped the trace, in flight since the sweep found it
 
     auto draw = [&]() {
         const double v = ring[r_head * 64 + lane];
@@ -505,7 +553,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
 #ifdef TMC_SECTION_TIMERS  // profiling builds only: wall time of the sections of a pass, section (debug_flags >> 8) & 7 -> counters[7]
     unsigned long long sec_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long sec_prev = __builtin_amdgcn_s_memtime();
-#define TMC_SEC(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sec_t[i] += now_ - sec_prev; sec_prev = now_; }
+#define TMC_SEC(i) { if (H.debug_flags & 4096) __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sec_t[i] += now_ - sec_prev; sec_prev = now_; }
 #else
 #define TMC_SEC(i)
 #endif
@@ -592,9 +640,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             } else {
                 interacted = true;
                 if (TRACK) {
-                    trk.before_nu = p.nu; trk.before_mu = p.mu; trk.before_energy = p.energy;
-                    trk.line_absorb_id = (type == IT_LINE) ? p.next_line_id : -1;
-                    trk.radius = p.r; trk.shell_id = p.shell; trk.interaction_type = type;
+                    // the tracker's record of the (so far) last interaction goes straight to the output arrays: the stores
+                    // are not waited for, and nothing of it has to stay in registers until the packet ends
+                    const DeviceProblem *C = &W->D;
+                    const long long i = chunk_first + pkt;
+                    C->li_before_nu[i] = p.nu; C->li_before_mu[i] = p.mu; C->li_before_energy[i] = p.energy;
+                    C->li_line_absorb_id[i] = (type == IT_LINE) ? p.next_line_id : -1;
+                    C->li_radius[i] = p.r; C->li_shell_id[i] = p.shell; C->li_interaction_type[i] = type;
                 }
                 // common part of line_scatter_event (interaction_event_callers.py:187-239) and thomson_scatter
                 // (interaction_events.py:184-217): Doppler with the old angle, new isotropic angle, Doppler back
@@ -609,7 +661,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (type == IT_LINE) {
                     emit = p.next_line_id;
                     if (P.line_interaction_type != 0) {
-                        const int2 blk = P.line_block[(unsigned)p.next_line_id];
+                        const int2 blk = LS ? pre_blk : P.line_block[(unsigned)p.next_line_id];
                         mb0 = blk.x; mb1 = blk.y;
                         in_macro = true;
                     }
@@ -784,8 +836,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 }
                 if (FULL) p.mu = aberration_cmf_to_lf(p.r, t, p.mu);
                 if (TRACK) {
-                    trk.line_emit_id = emit_id;
-                    trk.after_mu = p.mu;
+                    const DeviceProblem *C = &W->D;
+                    const long long i = chunk_first + pkt;
+                    C->li_line_emit_id[i] = emit_id;
+                    C->li_after_mu[i] = p.mu;
                     trk_count += 1 + trk_boundary;
                     trk_boundary = 0;
                     trk_any = true;
@@ -796,7 +850,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             if (VPK && interacted && !err) want_volley = true;
             if (err || p.status != ST_IN_PROCESS) {
                 const long long i = chunk_first + pkt;
-                const DeviceProblem *C = P.cold;
+                const DeviceProblem *C = &W->D;
                 if (err) {
                     atomicMin(&C->first_error[0], i);
                     C->out_nu[i] = (double)err;
@@ -808,19 +862,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     if (TRACK) {
                         const bool any = trk_any;
                         const double nan = __builtin_nan("");
-                        C->li_radius[i] = any ? trk.radius : nan;
                         C->li_nu[i] = any ? p.nu : nan;
                         C->li_energy[i] = any ? p.energy : nan;
-                        C->li_before_nu[i] = any ? trk.before_nu : nan;
-                        C->li_before_mu[i] = any ? trk.before_mu : nan;
-                        C->li_before_energy[i] = any ? trk.before_energy : nan;
                         C->li_after_nu[i] = any ? p.nu : nan;
-                        C->li_after_mu[i] = any ? trk.after_mu : nan;
                         C->li_after_energy[i] = any ? p.energy : nan;
-                        C->li_shell_id[i] = any ? trk.shell_id : -1;
-                        C->li_interaction_type[i] = any ? trk.interaction_type : -1;
-                        C->li_line_absorb_id[i] = any ? trk.line_absorb_id : -1;
-                        C->li_line_emit_id[i] = any ? trk.line_emit_id : -1;
+                        if (!any) {  // no interaction at all: the fields an interaction would have written
+                            C->li_radius[i] = nan; C->li_before_nu[i] = nan; C->li_before_mu[i] = nan; C->li_before_energy[i] = nan;
+                            C->li_after_mu[i] = nan;
+                            C->li_shell_id[i] = -1; C->li_interaction_type[i] = -1; C->li_line_absorb_id[i] = -1; C->li_line_emit_id[i] = -1;
+                        }
                         C->li_interactions_count[i] = trk_count;
                     }
                 }
@@ -832,53 +882,40 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         {
             const unsigned long long need_pkt = __ballot(state == WS_NEED_PACKET);
             if (need_pkt) {
-                long long base = chunk_count;
-                if (!exhausted) {
-                    const int n_want = __popcll(need_pkt);
+                // Packets are handed out from a block the wave has reserved (one atomic per WV_RESERVE packets, not per pass):
+                // the first lanes take what is left of the current block, the others start the next one.
+                const int n_want = __popcll(need_pkt);
+                const int n_old = (int)min((long long)n_want, res_end - res_next);
+                const long long old_next = res_next;
+                res_next += n_old;
+                long long new_base = chunk_count;
+                const int n_new = n_want - n_old;
+                if (n_new > 0 && !exhausted) {
+                    const int n_res = max(WV_RESERVE, n_new);
                     unsigned long long b = 0;
-                    if (lane == 0) b = atomicAdd(P.next_packet, (unsigned long long)n_want);
+                    if (lane == 0) b = atomicAdd(P.next_packet, (unsigned long long)n_res);
                     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b);
                     const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-                    base = (long long)(((unsigned long long)bhi << 32) | blo);
-                    if (base + n_want >= chunk_count) exhausted = true;
+                    const long long got = (long long)(((unsigned long long)bhi << 32) | blo);
+                    if (got + n_res >= chunk_count) exhausted = true;
+                    new_base = min(got, chunk_count);
+                    res_next = min(new_base + n_new, chunk_count);
+                    res_end = min(new_base + n_res, chunk_count);
                 }
                 if (state == WS_NEED_PACKET) {
-                    const long long mine = base + __popcll(need_pkt & ((1ull << lane) - 1ull));
+                    const int rank = __popcll(need_pkt & ((1ull << lane) - 1ull));
+                    const long long mine = rank < n_old ? old_next + rank : new_base + (rank - n_old);
                     if (mine >= chunk_count) state = WS_DONE;
                     else {
                         pkt = (int)mine;
                         r_gpos = r_head = r_cnt = 0;
-                        sh.rng_a[lane] = W->seeds[chunk_first + mine];  // mt[0]
-                        sh.rng_b[lane] = W->seed_checkpoint[mine];      // mt[397]
-                        const long long i = chunk_first + mine;
-                        const DeviceProblem *C = P.cold;
-                        p.r = C->r0[i]; p.mu = C->mu0[i]; p.nu = C->nu0[i]; p.energy = C->e0[i];
+                        const LaunchRec lr = W->launch[mine];
+                        sh.rng_a[lane] = lr.seed;        // mt[0]
+                        sh.rng_b[lane] = lr.checkpoint;  // mt[397]
+                        p.r = lr.r; p.mu = lr.mu; p.nu = lr.nu; p.energy = lr.energy;
+                        p.next_line_id = lr.line0;
                         p.shell = 0; p.status = ST_IN_PROCESS;
                         if (TRACK) { trk_count = 0; trk_boundary = 0; trk_any = false; }  // (-1 + the initial track_boundary_event)
-                        {   // set_packet_props_{partial,full}_relativity (classic/packet_propagation.py:254-318)
-                            const double velocity = p.r / t;
-                            const double inv = inverse_doppler_factor<FULL>(velocity, p.mu);
-                            if (FULL) {
-                                const double beta = velocity / C_LIGHT;
-                                p.nu *= inv; p.energy *= inv;
-                                p.mu = (p.mu + beta) / (1 + beta * p.mu);
-                            } else { p.nu *= inv; p.energy *= inv; }
-                        }
-                        {   // initialize_line_id (packets/radiative_packet.py:96-110) through the frequency-bucket index
-                            const double velocity = p.r / t;
-                            const double comov_nu = p.nu * doppler_factor<FULL>(velocity, p.mu);
-                            int lo;
-                            const long long kk = (long long)((unsigned long long)__double_as_longlong(comov_nu > 0.0 ? comov_nu : 0.0) >> P.bucket_shift) - P.bucket_kmin;
-                            if (kk >= P.bucket_n) lo = 0;
-                            else if (kk < 0) lo = L;
-                            else {
-                                lo = P.bucket_first[kk];
-                                const int hi = kk > 0 ? P.bucket_first[kk - 1] : L;
-                                while (lo < hi && P.nu_line[(unsigned)lo] >= comov_nu) ++lo;
-                            }
-                            if (lo == L) lo -= 1;
-                            p.next_line_id = lo;
-                        }
                         state = WS_NEED_TRACE;
                         if (VPK) { vseq = 0; pred_bits = 0; want_volley = true; }  // volley at launch (classic/packet_propagation.py:109-118)
                     }
@@ -910,7 +947,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 mu_bin = (1.0 - mu_min) / (double)n_v;
                 r_dop = doppler_factor<FULL>(p.r / t, p.mu);
             }
-            const DeviceProblem *C = P.cold;
+            const DeviceProblem *C = &W->D;
             // Pooled volley.  The v-packets of ALL volleys of the wave are work items for ALL 64 lanes, so a packet deep in
             // the ejecta (many shells per v-packet) does not make the lanes of shallow packets wait.  The n_v mu-draws and
             // the Russian-roulette draws come from the parent's stream in sequence, so an item reads its draws at the
@@ -1087,7 +1124,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     s_kp = ((chi_e * H.tc) / p.nu) * (1.0 + 0x1p-40);
                     s_xb = ((d_boundary * p.nu) * H.rcp_tc) * (1.0 - 0x1p-40);
                     s_fast = fast && mid_range(s_kp);
-                    s_exact = !s_fast || s_line >= L - 1;
                     s_active = true;
                 } else {
                     sh.nu[lane] = p.nu; sh.rcp_nu[lane] = 1.0 / p.nu; sh.comov_nu[lane] = comov_nu;
@@ -1128,15 +1164,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     for (int k = 0; k < LS_CHUNK; ++k) { nl[k] = pn[k]; tl[k] = pt[k]; }
                     int adv = 0;  // lines of this chunk the trace has passed
                     const double comov = p.nu * dop;
-                    if (s_exact) {
-                        s_exact = !s_fast;
+                    // lines that provably do not stop the trace (see above); the first one that might is kept in f_nu / f_tau
+                    const int n_fast = L - 1 - s_line;  // lines of the chunk before the last line of the list
+                    bool alive = s_fast;
+                    double f_nu = nl[0], f_tau = tl[0];
+#pragma unroll
+                    for (int k = 0; k < LS_CHUNK; ++k) {
+                        if (alive) {
+                            const double X = comov - nl[k];
+                            const double x = s_kp * X;
+                            const double D = s_tau_event - s_tau;
+                            const double tau_n = s_tau + tl[k];
+                            const double sum = tau_n + x;
+                            const bool ok = k < n_fast && X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
+                            if (ok) { s_tau = tau_n; ++adv; }
+                            else { alive = false; f_nu = nl[k]; f_tau = tl[k]; }
+                        }
+                    }
+                    visits += (unsigned long long)adv;
+                    if (!alive) {
+                        // that line with the reference's own arithmetic (or the for-else, once the list is exhausted)
                         const double chi = sh.d_cont0[lane], d_bound = sh.d_boundary[lane];
+                        const int line = s_line + adv;
                         int code;
                         double dist;
-                        if (s_line < L) {
+                        if (line < L) {
                             ++visits;
-                            code = lane_exact_line(H, s_line, nl[0], tl[0], s_tau, p.nu, comov, chi, s_tau_event, d_bound, dist);
-                            if (!code) { s_tau = s_tau + tl[0]; adv = 1; }
+                            code = lane_exact_line(H, line, f_nu, f_tau, s_tau, p.nu, comov, chi, s_tau_event, d_bound, dist);
+                            if (!code) { s_tau = s_tau + f_tau; ++adv; }
                         } else {
                             // for-else (lines 157-172): the line list is exhausted; next_line_id is left untouched (bit 3)
                             const double d_cont = (s_tau_event - s_tau) / chi;
@@ -1145,28 +1200,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             code = (cont ? 2 : 1) | 8;
                         }
                         if (code) {
-                            sh.d_boundary[lane] = dist; sh.res_info[lane] = code; sh.res_line[lane] = (code & 8) ? 0 : s_line;
+                            sh.d_boundary[lane] = dist; sh.res_info[lane] = code; sh.res_line[lane] = (code & 8) ? 0 : line;
+                            if (code == 3 && H.line_block) pre_blk = H.line_block[(unsigned)line];
                             s_active = false;
                         }
-                    }
-                    if (s_active && s_fast) {
-                        const int n_fast = L - 1 - s_line;  // lines of the chunk that are not the last line of the list
-                        bool alive = true;
-                        const int k0 = adv;
-#pragma unroll
-                        for (int k = 0; k < LS_CHUNK; ++k) {
-                            if (alive && (k > 0 || k0 == 0)) {
-                                const double X = comov - nl[k];
-                                const double x = s_kp * X;
-                                const double D = s_tau_event - s_tau;
-                                const double tau_n = s_tau + tl[k];
-                                const double sum = tau_n + x;
-                                const bool ok = k < n_fast && X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
-                                if (ok) { s_tau = tau_n; ++adv; } else alive = false;
-                            }
-                        }
-                        visits += (unsigned long long)(adv - k0);
-                        if (!alive) s_exact = true;
                     }
                     s_line += adv;
                 }
@@ -1234,7 +1271,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     }
 
     if (lane == 0 && W->log.region_capacity > 0) W->log.region_count[blockIdx.x] = min(log_used, W->log.region_capacity);
-    const DeviceProblem *C = W->P.cold;
+    const DeviceProblem *C = &W->D;
     for (int s = lane; s < H.n_shells; s += 64) {
         if (lds_J[s] != 0.0) atomic_add_f64(&C->J[s], lds_J[s]);
         if (lds_nubar[s] != 0.0) atomic_add_f64(&C->nubar[s], lds_nubar[s]);

@@ -125,7 +125,7 @@ struct TardisMcContext {
     // launch geometry
     int variant = -1;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel, group sweeps; 3: wave-owner kernel, lane sweeps; -1: automatic
     bool prob_negative = false;  // a negative transition probability: the running sums are not monotone, no jump search
-    int ls_min_active = 32, ls_max_steps = 64;  // lane sweeps: when to leave the sweep phase (propagate_wave.hpp)
+    int ls_min_active = 0, ls_max_steps = 1 << 30;  // lane sweeps: when to leave the sweep phase (propagate_wave.hpp)
     int blocks_per_cu = 16;
     int debug_flags = 0;
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
@@ -1179,9 +1179,17 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci], st));
             if (wave_kernel) {
                 // lazy seeding: only word 397 of every start state is precomputed; the refills continue the init_genrand chains
-                HIP_TRY(ctx, ctx->seed_chk[b].ensure((size_t)count * sizeof(uint32_t)));
-                hipLaunchKernelGGL(mc::seed_checkpoint_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
-                                   ctx->seeds.as<uint32_t>(), ctx->seed_chk[b].as<uint32_t>(), first, count);
+                HIP_TRY(ctx, ctx->seed_chk[b].ensure((size_t)count * sizeof(mc::LaunchRec)));
+                {
+                    mc::LaunchPrepArgs la{};
+                    la.r0 = F.r0; la.mu0 = F.mu0; la.nu0 = F.nu0; la.e0 = F.e0; la.nu_line = P.nu_line;
+                    la.seeds = ctx->seeds.as<uint32_t>();
+                    la.bucket_first = P.bucket_first; la.bucket_shift = P.bucket_shift; la.bucket_n = P.bucket_n; la.n_lines = P.n_lines;
+                    la.bucket_kmin = P.bucket_kmin; la.t_exp = P.t_exp;
+                    la.out = ctx->seed_chk[b].as<mc::LaunchRec>(); la.first = first; la.count = count;
+                    if (full) hipLaunchKernelGGL(mc::launch_prep_kernel<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, la);
+                    else hipLaunchKernelGGL(mc::launch_prep_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, la);
+                }
                 HIP_TRY(ctx, hipGetLastError());
             } else {
                 hipLaunchKernelGGL(mc::seed_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
@@ -1201,10 +1209,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 // cold arguments of this launch: one device slot per chunk (the host copies stay alive in ctx->wave_cold_host)
                 if ((int)ctx->wave_cold_host.size() <= ci) ctx->wave_cold_host.resize(ci + 1);
                 mc::WaveCold &wc = ctx->wave_cold_host[ci];
-                wc.P = P; wc.P.next_packet = next_packet; wc.log = lg; wc.seeded_states = seeded;
+                wc.P = P; wc.P.next_packet = next_packet; wc.D = F; wc.log = lg; wc.seeded_states = seeded;
                 wc.chunk_first = first; wc.chunk_count = count;
-                wc.seeds = ctx->seeds.as<uint32_t>();
-                wc.seed_checkpoint = ctx->seed_chk[b].as<uint32_t>();
+                wc.launch = ctx->seed_chk[b].as<mc::LaunchRec>();
                 if (vpk) HIP_TRY(ctx, ctx->vp_scratch.ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(mc::VpResult)));
                 wc.vp_scratch = ctx->vp_scratch.as<mc::VpResult>();
                 mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci;
@@ -1214,6 +1221,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
                 hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
                 hot.ls_min_active = ctx->ls_min_active; hot.ls_max_steps = ctx->ls_max_steps;
+                hot.line_block = P.line_interaction_type != 0 ? P.line_block : nullptr;
                 hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));

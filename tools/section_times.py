@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tardis_amd import synthetic
 from tardis_amd.engine import Engine
 
+EXTRA = int(os.environ.get("SEC_EXTRA", "0"))
 NAMES = ["cold+refill+log", "epilogue", "macro walk", "finish", "fetch(+volleys)", "prologue", "sweep"]
 kw = dict(synthetic.BASELINE_CONFIGS[2])
 kw["n_packets"] = int(sys.argv[1])
@@ -17,7 +18,7 @@ for spec in sys.argv[2:]:
         for kv in spec.split(","):
             k, v = kv.split("=")
             eng.set_option(k, int(v))
-        eng.set_option("debug_flags", 64 | (sec << 8))
+        eng.set_option("debug_flags", 64 | (sec << 8) | EXTRA)
         eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
         eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
         for i in range(2):
