@@ -149,7 +149,7 @@ def main():
     if pg.rank == 0:
         # dominant kernel = the propagation kernel; its launches of one step are timed with HIP events on the engine stream
         launches = max(ktimes["launches"], 1)
-        wave = args.variant in (None, 2)
+        wave = args.variant in (None, 2, 3)
         dominant = "propagate_wave_kernel" if wave else ("propagate_lane_kernel" if args.variant == 0 else "propagate_group_kernel")
         kernel_ms = ktimes["propagate_ms"] / launches
         # the dominant kernel's own algorithmic bytes (see algorithmic_bytes) over its HIP-event duration

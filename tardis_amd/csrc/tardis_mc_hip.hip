@@ -125,7 +125,7 @@ struct TardisMcContext {
     // launch geometry
     int variant = -1;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel, group sweeps; 3: wave-owner kernel, lane sweeps; -1: automatic
     bool prob_negative = false;  // a negative transition probability: the running sums are not monotone, no jump search
-    int ls_min_active = 0, ls_max_steps = 1 << 30;  // lane sweeps: when to leave the sweep phase (propagate_wave.hpp)
+    int ls_min_active = 8, ls_max_steps = 1 << 30;  // lane sweeps: when to leave the sweep phase (propagate_wave.hpp)
     int blocks_per_cu = 16;
     int debug_flags = 0;
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
@@ -985,7 +985,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
     // automatic choice: the wave-owner kernel (its pooled v-packet volleys take up to 32 v-packets per volley: one bit of
     // the roulette predictor each; beyond that the lane-per-packet kernel)
-    int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : 2);
+    // automatic choice: the wave-owner kernel, with lane sweeps where their bounds hold (partial relativity)
+    int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : (c.enable_full_relativity ? 2 : 3));
     if (ctx->prob_negative && (variant == 2 || variant == 3)) variant = 1;  // (the wave kernel searches the monotone running sums)
     const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2 || variant == 3) && (!vpk || c.number_of_vpackets <= 32);
 
