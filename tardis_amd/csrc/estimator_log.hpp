@@ -30,23 +30,6 @@ constexpr int EST_APRON = 256;       // lines past the end of a tile that are st
                                      // their bin's tile and may run on into the next one)
 constexpr int EST_MAX_BINS = 36864;  // largest LDS histogram of the binning kernels (dynamic LDS, 4 B per bin = 144 KiB)
 
-// the term update_line_estimators adds for line `nu_line` (estimators_line.py; the sweep's pend_e / pend_jb)
-template <bool FULL>
-__device__ __forceinline__ void line_estimator_terms(const LineVisitRecord &rec, bool fast, double rcp_nu, double nu_line, double t_exp,
-                                                     double tc, double rcp_tc, double &e_term, double &jb_term)
-{
-    if (FULL) e_term = rec.energy;
-    else {
-        const double nu_diff = rec.comov_nu - nu_line;
-        const double q = fast ? exact_div<true>(nu_diff, rec.nu, rcp_nu) : nu_diff / rec.nu;
-        const bool close = fabs(q) < CLOSE_LINE_THRESHOLD;
-        const double d_trace = close ? 0.0 : q * C_LIGHT * t_exp;
-        const double x = d_trace + rec.mur;
-        e_term = rec.energy * (1.0 - (fast ? exact_div<true>(x, tc, rcp_tc) : x / tc));
-    }
-    jb_term = fast ? exact_div<true>(e_term, rec.nu, rcp_nu) : e_term / rec.nu;
-}
-
 __global__ void __launch_bounds__(256) bin_count_kernel(const unsigned *__restrict__ keys, const unsigned *__restrict__ region_count,
                                                         int n_regions, unsigned region_capacity, int n_bins, unsigned *__restrict__ bin_count)
 {
@@ -126,20 +109,6 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(const unsigned *__rest
 constexpr int EST_LONG = 63;
 constexpr int ACC_WAVES = 8;
 
-template <bool FULL, bool FAST>
-__device__ __forceinline__ void accumulate_term(double energy, double nu, double rcp_nu, double comov_nu, double mur, double nu_l,
-                                                double t_exp, double tc, double rcp_tc, double &e_term, double &jb_term)
-{
-    if (FULL) e_term = energy;
-    else {
-        const double q = exact_div<FAST>(comov_nu - nu_l, nu, rcp_nu);
-        const bool close = fabs(q) < CLOSE_LINE_THRESHOLD;
-        const double d_trace = close ? 0.0 : q * C_LIGHT * t_exp;
-        e_term = energy * (1.0 - exact_div<FAST>(d_trace + mur, tc, rcp_tc));
-    }
-    jb_term = exact_div<FAST>(e_term, nu, rcp_nu);
-}
-
 template <bool FULL>
 __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVisitRecord *__restrict__ records,
                                                                     const unsigned *__restrict__ sorted_index,
@@ -152,7 +121,7 @@ __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVi
     constexpr int TILE_LDS = EST_TILE + EST_APRON;
     __shared__ double tile_jb[TILE_LDS], tile_ed[TILE_LDS];
     // staged records, array of structures: a lane fetches "its" record with three 16-byte LDS reads
-    struct __attribute__((aligned(16))) Staged { double energy, nu, rcp_nu, comov_nu, mur; unsigned idx0, first_fast; };
+    struct __attribute__((aligned(8))) Staged { double c_e, c_jb; unsigned idx0, first; };
     __shared__ Staged staged[ACC_WAVES][64];
     __shared__ unsigned long long starts[ACC_WAVES][64];
     const unsigned n_slices = slice_start[n_bins];
@@ -175,19 +144,21 @@ __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVi
         for (int k = threadIdx.x; k < TILE_LDS; k += 64 * ACC_WAVES) { tile_jb[k] = 0.0; tile_ed[k] = 0.0; }
         __syncthreads();
 
-        auto add_term = [&](unsigned idx, double jb_term, double e_term) {
+        // (the tile accumulates the traces' constants; the factor nu_line is applied when the tile is flushed)
+        auto add_term = [&](unsigned idx, double c_jb, double c_e) {
             const unsigned off = idx - tile_idx0;
             if (off < tile_len) {
-                atomicAdd(&tile_jb[off], jb_term);
-                atomicAdd(&tile_ed[off], e_term);
+                atomicAdd(&tile_jb[off], c_jb);
+                atomicAdd(&tile_ed[off], c_e);
             } else {  // the trace ran far past the end of its first tile
-                atomic_add_f64(&jblue_t[idx], jb_term);
-                atomic_add_f64(&edot_t[idx], e_term);
+                const double f = FULL ? 1.0 : nu_line[idx - row];
+                atomic_add_f64(&jblue_t[idx], c_jb * f);
+                atomic_add_f64(&edot_t[idx], c_e * f);
             }
         };
         auto fetch = [&](unsigned r) {
             LineVisitRecord rec;
-            rec.n_flags = 0;
+            rec.c_e = rec.c_jb = 0.0; rec.idx0 = 0; rec.n = 0;
             if (r < rec_last) rec = records[sorted_index[r]];
             return rec;
         };
@@ -198,8 +169,7 @@ __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVi
             const LineVisitRecord rec = next;
             next = next2;
             next2 = fetch(base + 2 * stride + (unsigned)lane);
-            const unsigned n_all = rec.n_flags & 0x7fffffffu;
-            const bool fast = (rec.n_flags >> 31) != 0;
+            const unsigned n_all = rec.n;
             const unsigned n = n_all > (unsigned)EST_LONG ? 0u : n_all;  // long records are handled below
             // exclusive scan of n over the wave
             unsigned incl = n;
@@ -212,16 +182,13 @@ __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVi
             const unsigned total = (unsigned)__shfl((int)incl, 63);
             const unsigned n_pass = (total + 63) >> 6;  // <= EST_LONG
             starts[w][lane] = 0ull;
-            const double rcp_nu = 1.0 / rec.nu;
             if (n) {  // staged in compacted order: the q-th record that starts is the q-th staged one
                 const int pos = __popcll(__ballot(true) & ((1ull << lane) - 1ull));
                 Staged st;
-                st.energy = rec.energy; st.nu = rec.nu; st.rcp_nu = rcp_nu; st.comov_nu = rec.comov_nu; st.mur = rec.mur;
-                st.idx0 = rec.idx0; st.first_fast = excl | (fast ? 0x80000000u : 0u);
+                st.c_e = rec.c_e; st.c_jb = rec.c_jb; st.idx0 = rec.idx0; st.first = excl;
                 staged[w][pos] = st;
                 atomicOr(&starts[w][excl >> 6], 1ull << (excl & 63));
             }
-            const bool all_fast = __ballot(n != 0 && !fast) == 0ull;
             unsigned rec_base = 0;  // records started before this pass (wave-uniform)
             for (unsigned i = 0; i < n_pass; ++i) {
                 const unsigned long long m = starts[w][i];
@@ -229,12 +196,8 @@ __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVi
                 if (t < total) {
                     const unsigned q = rec_base + (unsigned)__popcll(m & le_mask) - 1u;
                     const Staged st = staged[w][q];
-                    const unsigned idx = st.idx0 + (t - (st.first_fast & 0x7fffffffu));
-                    const double nu_l = nu_line[idx - row];
-                    double e_term, jb_term;
-                    if (all_fast || (st.first_fast >> 31)) accumulate_term<FULL, true>(st.energy, st.nu, st.rcp_nu, st.comov_nu, st.mur, nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
-                    else accumulate_term<FULL, false>(st.energy, st.nu, st.rcp_nu, st.comov_nu, st.mur, nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
-                    add_term(idx, jb_term, e_term);
+                    const unsigned idx = st.idx0 + (t - st.first);
+                    add_term(idx, st.c_jb, st.c_e);
                 }
                 rec_base += (unsigned)__popcll(m);
             }
@@ -245,23 +208,15 @@ __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVi
                 longs &= longs - 1;
                 const unsigned len = (unsigned)__shfl((int)n_all, q);
                 const unsigned idx0 = (unsigned)__shfl((int)rec.idx0, q);
-                const bool l_fast = __shfl((int)fast, q) != 0;
-                const double l_energy = __shfl(rec.energy, q), l_nu = __shfl(rec.nu, q), l_rcp = __shfl(rcp_nu, q);
-                const double l_cnu = __shfl(rec.comov_nu, q), l_mur = __shfl(rec.mur, q);
-                for (unsigned k = lane; k < len; k += 64) {
-                    const unsigned idx = idx0 + k;
-                    const double nu_l = nu_line[idx - row];
-                    double e_term, jb_term;
-                    if (l_fast) accumulate_term<FULL, true>(l_energy, l_nu, l_rcp, l_cnu, l_mur, nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
-                    else accumulate_term<FULL, false>(l_energy, l_nu, l_rcp, l_cnu, l_mur, nu_l, t_exp, tc, rcp_tc, e_term, jb_term);
-                    add_term(idx, jb_term, e_term);
-                }
+                const double l_ce = __shfl(rec.c_e, q), l_cjb = __shfl(rec.c_jb, q);
+                for (unsigned k = lane; k < len; k += 64) add_term(idx0 + k, l_cjb, l_ce);
             }
         }
         __syncthreads();
         for (unsigned k = threadIdx.x; k < tile_len; k += 64 * ACC_WAVES) {
-            if (tile_jb[k] != 0.0) atomic_add_f64(&jblue_t[tile_idx0 + k], tile_jb[k]);
-            if (tile_ed[k] != 0.0) atomic_add_f64(&edot_t[tile_idx0 + k], tile_ed[k]);
+            const double f = FULL ? 1.0 : nu_line[tile_idx0 - row + k];
+            if (tile_jb[k] != 0.0) atomic_add_f64(&jblue_t[tile_idx0 + k], tile_jb[k] * f);
+            if (tile_ed[k] != 0.0) atomic_add_f64(&edot_t[tile_idx0 + k], tile_ed[k] * f);
         }
         __syncthreads();
     }

@@ -21,13 +21,18 @@ enum : int { ERR_MONTECARLO = -3, ERR_MACRO_ATOM = -4, ERR_UNSUPPORTED = -5 };
 constexpr int MT_N = 624;
 
 // ---- deferred line-estimator accumulation (estimator_log.hpp): one record per trace
-struct __attribute__((aligned(16))) LineVisitRecord {
-    double energy, nu, comov_nu, mur;  // packet state at the start of the trace (mur = mu * r)
-    unsigned idx0;                     // shell * n_lines + first line visited
-    unsigned n_flags;                  // number of lines visited | (exact-division fast path << 31)
-    unsigned pad[2];
+// In partial relativity the term update_line_estimators adds for a visited line, energy * (1 - (d_line + mu r) / (t c)),
+// is energy * nu_line / nu exactly (d_line is where the packet's comoving frequency equals nu_line), i.e. a per-trace
+// constant times nu_line; in full relativity it is the energy itself.  The record therefore carries the two constants
+// (Edotlu and j_blue) and the range of lines; the factor nu_line is applied once per line when a tile is flushed.  The sums
+// agree with the reference's to rounding (<= ~1e-14 relative per term: the reference's own rounding and its d = 0 for
+// lines closer than 1e-14), far inside the summation-order tolerance the estimators are compared with.
+struct __attribute__((aligned(8))) LineVisitRecord {
+    double c_e, c_jb;   // Edotlu / j_blue constants of the trace (energy / nu, energy / nu^2; full relativity: energy, energy / nu)
+    unsigned idx0;      // shell * n_lines + first line visited
+    unsigned n;         // number of lines visited
 };
-static_assert(sizeof(LineVisitRecord) == 48, "record layout");
+static_assert(sizeof(LineVisitRecord) == 24, "record layout");
 
 struct EstimatorLog {
     LineVisitRecord *records;          // [n_regions][region_capacity]: every wave appends to its own region (no atomics)

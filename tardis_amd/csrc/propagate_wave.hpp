@@ -595,22 +595,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 log_used += (unsigned)__popcll(have);
                 if (n_visit > 0) {
                     LineVisitRecord rec;
-                    rec.energy = p.energy; rec.nu = p.nu; rec.comov_nu = p.nu * dop; rec.mur = p.mu * p.r;
+                    const double inv_nu = 1.0 / p.nu;
+                    rec.c_e = FULL ? p.energy : p.energy * inv_nu;
+                    rec.c_jb = rec.c_e * inv_nu;
                     rec.idx0 = (unsigned)p.shell * (unsigned)L + (unsigned)start;
-                    rec.n_flags = (unsigned)n_visit | ((unsigned)(pflags & 1) << 31);
-                    rec.pad[0] = rec.pad[1] = 0;
+                    rec.n = (unsigned)n_visit;
                     if (my < log.region_capacity) {
                         const size_t slot = (size_t)blockIdx.x * log.region_capacity + my;
                         log.records[slot] = rec;
                         log.keys[slot] = (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE);
                     } else {  // region full (or no log): add the terms directly (slow path)
-                        const bool fast = (pflags & 1) != 0;
-                        const double rcp_nu = 1.0 / rec.nu;
                         for (int k = 0; k < n_visit; ++k) {
-                            double e_term, jb_term;
-                            line_estimator_terms<FULL>(rec, fast, rcp_nu, P.nu_line[(unsigned)(start + k)], t, P.tc, P.rcp_tc, e_term, jb_term);
-                            atomic_add_f64(&jb[rec.idx0 + (unsigned)k], jb_term);
-                            atomic_add_f64(&ed[rec.idx0 + (unsigned)k], e_term);
+                            const double f = FULL ? 1.0 : P.nu_line[(unsigned)(start + k)];
+                            atomic_add_f64(&jb[rec.idx0 + (unsigned)k], rec.c_jb * f);
+                            atomic_add_f64(&ed[rec.idx0 + (unsigned)k], rec.c_e * f);
                         }
                     }
                 }
