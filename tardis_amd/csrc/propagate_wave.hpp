@@ -39,19 +39,21 @@ constexpr int WV_RESERVE = 32;  // packets a wave reserves per atomic on the chu
 struct WaveShared {
     double nu[64], rcp_nu[64], comov_nu[64], chi[64], rcp_chi[64], tau_event[64], d_cont0[64];
     double d_boundary[64];  // in: boundary distance of the prepared trace; out: distance of the event found
-    int cursor[64], rowfast[64];  // first line of the trace; shell * n_lines | exact-division fast path << 31
     int res_info[64], res_line[64];
-    int queue[64];                // lanes whose prepared trace waits for a worker group
     unsigned rng_a[64], rng_b[64];  // lazy MT19937 seeding: init_genrand words mt[k] and mt[k+397] of the next block to regenerate
+    // group sweeps only (the lane-sweep instantiations do not allocate the rest: 16 instead of 15 waves fit a CU's LDS)
+    int cursor[64], rowfast[64];  // first line of the trace; shell * n_lines | exact-division fast path << 31
+    int queue[64];                // lanes whose prepared trace waits for a worker group
 };
+constexpr size_t WAVE_SHARED_LS_BYTES = sizeof(WaveShared) - 3 * 64 * sizeof(int);
 struct WaveSharedFull {  // only read by the full-relativity sweep
     double r[64], mu[64];
 };
 
-template <bool FULL, bool VPK>
+template <bool FULL, bool VPK, bool LS = false>
 __host__ __device__ constexpr size_t wave_kernel_lds_bytes(int n_shells)
 {
-    return sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0) + (size_t)(VPK ? WV_RING_VPK : WV_RING) * 64 * sizeof(double) +
+    return (LS ? WAVE_SHARED_LS_BYTES : sizeof(WaveShared)) + (FULL ? sizeof(WaveSharedFull) : 0) + (size_t)(VPK ? WV_RING_VPK : WV_RING) * 64 * sizeof(double) +
            (size_t)5 * (size_t)n_shells * sizeof(double);  // J, nu_bar, r_inner, r_outer, n_e
 }
 
@@ -440,9 +442,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     WaveShared &sh = *reinterpret_cast<WaveShared *>(lds_raw);
-    WaveSharedFull &shf = *reinterpret_cast<WaveSharedFull *>(lds_raw + sizeof(WaveShared));
+    constexpr size_t SH_BYTES = LS ? WAVE_SHARED_LS_BYTES : sizeof(WaveShared);
+    WaveSharedFull &shf = *reinterpret_cast<WaveSharedFull *>(lds_raw + SH_BYTES);
     constexpr int RING = VPK ? WV_RING_VPK : WV_RING;  // look-ahead doubles per packet
-    double *ring = reinterpret_cast<double *>(lds_raw + sizeof(WaveShared) + (FULL ? sizeof(WaveSharedFull) : 0));  // [RING][64]
+    double *ring = reinterpret_cast<double *>(lds_raw + SH_BYTES + (FULL ? sizeof(WaveSharedFull) : 0));  // [RING][64]
     double *lds_J = ring + RING * 64;
     double *lds_nubar = lds_J + H.n_shells;
     double *lds_geo = lds_nubar + H.n_shells;  // r_inner | r_outer | n_e
@@ -670,7 +673,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         // ---- macro_atom_interaction (macro_atom.py:52-104): one jump of every walking packet per round.  The reference adds
         // the block's probabilities up until the sum exceeds the drawn number; the sums are precomputed (cum_t, same
         // additions in the same order), so the jump is the first entry of the block's monotone run that exceeds it:
-        // the first four entries in one round trip (the short blocks of downbranch end there), then a 4-ary search.
+        // the first eight entries in one round trip (the short blocks of downbranch end there), then a 4-ary search.
         if (P.line_interaction_type == 2 && !(P.debug_flags & 128)) {  // (flag 128: the per-lane search below, for tests)
             // macroatom mode (long chains of jumps, and a wave waits for its longest chain: one coalesced round trip per jump): the wave's G-lane groups scan the blocks, G
             // probabilities per coalesced load, accumulated in the reference's serial order (macro_atom_group() of the
@@ -775,33 +778,31 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         bool have_emit_nu = false;
         double emit_nu = 0.0;
         {
-            bool searching = false;  // the first four entries did not decide this lane's jump: 4-ary search in [lo, hi)
+            bool searching = false;  // the first eight entries did not decide this lane's jump: 4-ary search in [lo, hi)
             int lo = 0, hi = 0;      // cum[j] <= event for all block entries j < lo; hi == mb1 or cum[hi] > event
             double event = 0.0;
             while (__ballot(in_macro)) {
                 refill(__ballot(in_macro && !searching && r_cnt < 1), seeded_states);
                 if (in_macro) {
                     const double *__restrict__ cum = P.cum_t + (unsigned)p.shell * (unsigned)P.n_trans;
-                    // one round trip per round for every walking lane, whichever stage it is in
-                    int i0, i1, i2, i3;
-                    if (!searching) {
-                        event = draw();
-                        const int last = mb1 - 1;
-                        i0 = max(min(mb0, last), 0); i1 = max(min(mb0 + 1, last), 0); i2 = max(min(mb0 + 2, last), 0); i3 = max(min(mb0 + 3, last), 0);
-                    } else {
-                        const int n = hi - lo;
-                        i0 = lo + (n >> 2); i1 = lo + (n >> 1); i2 = lo + ((3 * n) >> 2); i3 = i2;
-                    }
-                    const double a0 = cum[(unsigned)i0], a1 = cum[(unsigned)i1], a2 = cum[(unsigned)i2], a3 = cum[(unsigned)i3];
                     int k = -2;  // >= 0: the jump goes to transition k; -1: no entry exceeds the number drawn; -2: search on
                     if (!searching) {
+                        // the first eight running sums of the block in one round trip (the table carries eight entries of
+                        // slack, entries past the end of the block are ignored)
+                        event = draw();
+                        const double *__restrict__ c8 = cum + (unsigned)mb0;
+                        double a8[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) a8[q] = c8[q];
                         k = -1;
-                        if (mb0 + 3 < mb1 && a3 > event) k = mb0 + 3;
-                        if (mb0 + 2 < mb1 && a2 > event) k = mb0 + 2;
-                        if (mb0 + 1 < mb1 && a1 > event) k = mb0 + 1;
-                        if (mb0 < mb1 && a0 > event) k = mb0;
-                        if (k < 0 && mb1 - mb0 > 4) { searching = true; lo = mb0 + 4; hi = mb1; k = -2; }
+#pragma unroll
+                        for (int q = 7; q >= 0; --q)
+                            if (mb0 + q < mb1 && a8[q] > event) k = mb0 + q;
+                        if (k < 0 && mb1 - mb0 > 8) { searching = true; lo = mb0 + 8; hi = mb1; k = -2; }
                     } else {
+                        const int n = hi - lo;
+                        const int i0 = lo + (n >> 2), i1 = lo + (n >> 1), i2 = lo + ((3 * n) >> 2);
+                        const double a0 = cum[(unsigned)i0], a1 = cum[(unsigned)i1], a2 = cum[(unsigned)i2];
                         if (a0 > event) hi = i0;
                         else if (a1 > event) { lo = i0 + 1; hi = i1; }
                         else if (a2 > event) { lo = i1 + 1; hi = i2; }

@@ -653,7 +653,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     {   // running sums of the transition probabilities within their blocks (macro_cumulative_kernel)
-        HIP_TRY(ctx, ctx->cum_t.ensure(T * S * sizeof(double)));
+        HIP_TRY(ctx, ctx->cum_t.ensure((T * S + 8) * sizeof(double)));  // (+8: the jump search reads eight entries at a time)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->cum_t.p, ctx->prob_t.p, T * S * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         ctx->prob_negative = false;
         if (macro && E > 1) {
@@ -1068,7 +1068,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         using KernelFn = void (*)(mc::GroupArgs, uint32_t *, long long, long long);
         KernelFn k;
         const bool full = c.enable_full_relativity != 0, trk = ctx->track;
-        const size_t wave_lds = vpk ? (full ? mc::wave_kernel_lds_bytes<true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, true>(ctx->n_shells))
+        const bool lane_sweep = variant == 3 && !full;  // (the bounds of the lane sweep are those of partial relativity)
+        const size_t wave_lds = lane_sweep ? (vpk ? mc::wave_kernel_lds_bytes<false, true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false, true>(ctx->n_shells))
+                              : vpk ? (full ? mc::wave_kernel_lds_bytes<true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, true>(ctx->n_shells))
                                     : (full ? mc::wave_kernel_lds_bytes<true, false>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false>(ctx->n_shells));
         if (wave_kernel && wave_lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
         const int wave_waves_per_cu = std::max(1, std::min(ctx->waves_per_simd > 0 ? 4 * ctx->waves_per_simd : 16, (int)((160 * 1024) / wave_lds)));
@@ -1085,7 +1087,6 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 #define TMC_PICKLS(G_, V_) (trk ? mc::propagate_wave_kernel<false, true, G_, V_, true> : mc::propagate_wave_kernel<false, false, G_, V_, true>)
         // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel)
         const int GW = ctx->group_size ? ctx->group_size : (ctx->n_lines <= 100000 ? 8 : 16);
-        const bool lane_sweep = variant == 3 && !full;  // (the bounds of the lane sweep are those of partial relativity)
         if (wave_kernel && lane_sweep) kw = (GW == 16) ? (vpk ? TMC_PICKLS(16, true) : TMC_PICKLS(16, false)) : (vpk ? TMC_PICKLS(8, true) : TMC_PICKLS(8, false));
         else if (wave_kernel) kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
 #undef TMC_PICKLS
