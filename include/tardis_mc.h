@@ -149,7 +149,9 @@ void tardis_mc_destroy(TardisMcContext *ctx);
 const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NULL: last create() error */
 
 /* Tunables.  name: "track_last_interaction" (0/1, default 1), "vpacket_log_capacity" (entries),
- * "variant" (kernel variant id), "blocks_per_cu", "estimator_copies" (1..8 private j_blue/Edotlu copies),
+ * "variant" (kernel variant: -1 automatic, 0 lane-per-packet, 1 group-per-packet, 2 wave-owner with group sweeps, 3 wave-owner
+ * with lane sweeps), "lane_sweep_min_active" / "lane_sweep_max_steps" (when variant 3 leaves its sweep phase),
+ * "blocks_per_cu", "estimator_copies" (1..8 private j_blue/Edotlu copies),
  * "debug_flags" (profiling experiments only: 1 skips the j_blue/Edotlu atomics, 2 the J/nu_bar updates). */
 int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value);
 
