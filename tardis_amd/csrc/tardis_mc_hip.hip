@@ -985,8 +985,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
     // automatic choice: the wave-owner kernel (its pooled v-packet volleys take up to 32 v-packets per volley: one bit of
     // the roulette predictor each; beyond that the lane-per-packet kernel)
-    // automatic choice: the wave-owner kernel, with lane sweeps where their bounds hold (partial relativity)
-    int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : (c.enable_full_relativity ? 2 : 3));
+    // automatic choice: the wave-owner kernel; lane sweeps where their bounds hold (partial relativity) and where they were
+    // measured to win: short traces between events (downbranch / scatter line lists, no volleys).  The macroatom shapes
+    // (5e5 lines, ~36 lines per trace, chains of ~20 jumps per interaction) run 19 % faster with group sweeps.
+    const bool prefer_lane_sweeps = !c.enable_full_relativity && !vpk && c.line_interaction_type != 2;
+    int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : (prefer_lane_sweeps ? 3 : 2));
     if (ctx->prob_negative && (variant == 2 || variant == 3)) variant = 1;  // (the wave kernel searches the monotone running sums)
     const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2 || variant == 3) && (!vpk || c.number_of_vpackets <= 32);
 
