@@ -1,26 +1,25 @@
-// propagate_wave.hpp -- wave-owner propagation kernel (variant 2): every LANE owns a packet, the wave's G-lane groups
-// are a pool of line-sweep workers.
+// propagate_wave.hpp -- wave-owner propagation kernel (variants 2 and 3): every LANE owns a packet.
 //
 // Why (measured on the group kernel, profiles/r01_*): with one packet per G-lane group, (a) the packet's scalar event
 // code (boundary distance, tau_event, move, scatter, macro atom) is executed redundantly by all G lanes, i.e. a
 // 64-lane wave retires 64/G events per pass through ~700 instructions, and (b) the wave's groups sweep in lockstep, so
-// every trace costs the MAXIMUM number of G-line steps over the wave's groups (~2.3x the mean for the exponential-like
-// sweep lengths of a Sobolev line list).  Here the two kinds of work are separated:
+// every trace costs the MAXIMUM number of G-line steps over the wave's groups.  Here the two kinds of work are separated:
 //
-//   event phase  -- lane-per-packet: all 64 lanes run the scalar event code for 64 different packets at once
-//                   (epilogue of the finished trace, macro atom, packet hand-over, prologue of the next trace).
-//   sweep phase  -- the 64/G groups take the prepared traces from the wave's pool one after the other: a group that
-//                   finds its stopping line immediately continues with the next waiting packet, whose first lines
-//                   were prefetched while the previous sweep was still running.  All groups stay busy until the pool
-//                   is empty, so the sweep cost follows the MEAN sweep length.
+//   event phase  -- lane-per-packet: all 64 lanes run the scalar event code for 64 different packets at once (log
+//                   record and epilogue of the finished trace, macro-atom jump, packet hand-over, prologue of the next trace).
+//   sweep phase  -- lane sweeps (LS instantiations, partial relativity): every lane sweeps the line list of its own packet,
+//                   eight lines per step, proving for each line that the reference's stop tests come out negative and
+//                   evaluating only the stopping line with the reference's arithmetic (see lane_exact_line below);
+//                -- group sweeps (full relativity): the 64/G groups take the prepared traces from the wave's pool one
+//                   after the other, a group that finds its stopping line continues with the next waiting packet.
 //
-// The arithmetic of a trace is the group kernel's (same operation order, same serial optical-depth scan), so per-packet
-// results stay bit-identical to the CPU oracle.  Sweep parameters travel from the owner lane to the worker group
-// through LDS (written once in the prologue); the stopping line / distance come back through LDS.  The line estimators
-// are not updated by the sweep at all: the owner lane logs one record per trace and the kernels of estimator_log.hpp
-// turn the log into j_blue / Edotlu (the memory-side fp64 atomics were what bounded the group kernel).  MT19937: the packet's state stays in global memory (seeded by
-// seed_states_kernel) and is advanced 8 words at a time by 8-lane subgroups with coalesced accesses; the tempered
-// doubles are parked in a per-lane LDS ring from which the lane-per-packet code pops its draws.
+// The arithmetic that decides a trace is the reference's (same operation order, same serial optical-depth sum), so
+// per-packet results stay bit-identical to the CPU oracle.  The line estimators are not updated by the sweep at all: the
+// owner lane logs one record per trace and the kernels of estimator_log.hpp turn the log into j_blue / Edotlu (the
+// memory-side fp64 atomics were what bounded the group kernel).  MT19937: launch_prep_kernel precomputes one word of the
+// start state per packet, a lane regenerates the next 8 words of its packet's state itself (refill) and parks the tempered
+// doubles in a per-lane LDS ring from which the event code pops its draws.  The kernel is bound by dependent memory
+// round trips: most of its structure exists to have fewer of them per pass.
 #pragma once
 #include "mc_device.hpp"
 #include "propagate_group.hpp"
@@ -183,7 +182,7 @@ __device__ __forceinline__ void sweep_step(const WaveHot &P, SweepSlot &s, const
 // so the line cannot stop the trace and only tau_incl = tau_prev + tau_line (the reference's serial sum) is carried on:
 // 5 flops and 4 compares per line instead of two divisions and the full predicate.  The first line that fails one of the
 // bounds (and the last line of the list, and every line of a trace whose operands are outside mid_range) is evaluated
-// with the reference's own arithmetic by lane_exact_line() at the start of the lane's next step.
+// with the reference's own arithmetic by lane_exact_line() in the same step.
 __device__ __forceinline__ int lane_exact_line(const WaveHot &P, int line, double nu_line, double tau_line, double tau_prev, double nu,
                                                double comov_nu, double chi, double tau_event, double d_boundary, double &distance)
 {   // trace_packet's loop body for one line (modes/homologous_rad_packet_transport.py:100-156), as in sweep_step(); the two

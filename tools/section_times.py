@@ -8,7 +8,7 @@ from tardis_amd.engine import Engine
 
 EXTRA = int(os.environ.get("SEC_EXTRA", "0"))
 NAMES = ["cold+refill+log", "epilogue", "macro walk", "finish", "fetch(+volleys)", "prologue", "sweep"]
-kw = dict(synthetic.BASELINE_CONFIGS[2])
+kw = dict(synthetic.BASELINE_CONFIGS[int(os.environ.get("SEC_CONFIG", "2"))])
 kw["n_packets"] = int(sys.argv[1])
 prob = synthetic.make_problem(seed=1, **kw)
 for spec in sys.argv[2:]:
