@@ -423,3 +423,36 @@ def test_config5_shape_small(oracle):
     assert_allclose(got.v_packets_energy_hist, ref.v_packets_energy_hist, rtol=EST_RTOL)
     for k in ("line_visits", "events", "macro_transitions", "vpacket_line_visits", "vpackets", "rng_draws"):
         assert got.counters[k] == ref.counters[k], k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["downbranch", "macroatom"])
+def test_negative_transition_probability_keeps_the_serial_walk(oracle, mode):
+    """The wave kernel searches the running sums of the transition probabilities, which presumes they are monotone.  A table
+    with a negative entry (the reference just keeps adding) is detected when the sums are built and the problem runs on the
+    kernel that walks the block serially: same jumps as the oracle."""
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=23, n_packets=20_000, n_shells=8, n_lines=4_000, line_interaction_type=mode)
+    # in some blocks the first probability becomes negative and the last one takes up the difference: the running sum dips
+    # below zero first but still ends at the block's total, so no packet runs out of its block
+    tp = prob.opacity_state.transition_probabilities
+    edges = np.asarray(prob.opacity_state.macro_block_edge_index)
+    n_changed = 0
+    for b in range(0, len(edges) - 1, 7):
+        lo, hi = int(edges[b]), int(edges[b + 1])
+        if hi - lo >= 3:
+            first = tp[lo, :].copy()
+            tp[lo, :] = -0.1 * first
+            tp[hi - 1, :] += 1.1 * first
+            n_changed += 1
+    assert n_changed > 0
+    ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
+    eng = Engine(0)
+    eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+    eng.reset_estimators(); eng.propagate(); eng.synchronize()
+    got = eng.get_results(track_last_interaction=True)
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
+        assert got.counters[k] == ref.counters[k], k
+    eng.close()
