@@ -341,6 +341,12 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
     double chi_cont = chi_e;
     if (FULL) chi_cont *= dop;
     double tau_shell = chi_cont * d_boundary;
+    // the frequency bucket of the shell boundary needs nothing that is still in flight: its lookup travels with the loads
+    // above instead of forming a round trip of its own after them
+    const double nu_thr = comov_nu - d_boundary * P.rcp_tc * v.nu;
+    long long kk_b = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
+    kk_b = kk_b < 0 ? 0 : (kk_b >= P.bucket_n ? P.bucket_n - 1 : kk_b);
+    const int bucket_e = P.bucket_first[kk_b];
     // calculate_distance_line (calculate_distances.py:66-112) of line k (frequency nl) for this v-packet
     auto d_line_of = [&](int k, double nl) -> double {
         if (FULL) {
@@ -363,10 +369,7 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
         if (!(d_boundary <= d_line)) {
             // first line after `start` whose resonance lies at or beyond the shell boundary (monotone along the list):
             // the frequency-bucket index gives a guess, a window of four lines around it is tested in one round trip
-            const double nu_thr = comov_nu - d_boundary * P.rcp_tc * v.nu;
-            long long kk = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
-            kk = kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
-            e = max(P.bucket_first[kk], start + 1);
+            e = max(bucket_e, start + 1);
             if (e > L - 1) e = L - 1;
             const int w0 = max(e - 1, start + 1);
             bool sw[4];
