@@ -711,7 +711,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (lane / G < n_items) {
                     item_of(lane / G, n_o, n_row, n_b0, n_b1, n_event);
                     const int kk = n_b0 + j;
-                    if (kk < n_b1) { n_pr = P.prob_t[n_row + (unsigned)kk]; n_rec = P.trans_rec[(unsigned)kk]; }
+                    if (kk < n_b1) { n_pr = P.cum_t[n_row + (unsigned)kk]; n_rec = P.trans_rec[(unsigned)kk]; }
                 }
                 for (int base = 0; base < n_items; base += 64 / G) {
                     const int o = n_o, b0 = n_b0, b1 = n_b1;
@@ -725,10 +725,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     if (base + 64 / G + lane / G < n_items) {
                         item_of(base + 64 / G + lane / G, n_o, n_row, n_b0, n_b1, n_event);
                         const int kk = n_b0 + j;
-                        if (kk < n_b1) { n_pr = P.prob_t[n_row + (unsigned)kk]; n_rec = P.trans_rec[(unsigned)kk]; }
+                        if (kk < n_b1) { n_pr = P.cum_t[n_row + (unsigned)kk]; n_rec = P.trans_rec[(unsigned)kk]; }
                     }
                     if (have) {
-                        double carry = 0.0;
                         int cnt = 0;
                         bool found = false;
                         int4 hit_rec = make_int4(0, 0, 0, 0);
@@ -736,10 +735,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             const int kk = b + j;
                             const bool in = kk < b1;
                             if (b != b0) {
-                                pr = in ? P.prob_t[row + (unsigned)kk] : 0.0;
+                                pr = in ? P.cum_t[row + (unsigned)kk] : 0.0;
                                 rec = in ? P.trans_rec[(unsigned)kk] : make_int4(0, 0, 0, 0);
                             }
-                            const double acc = serial_prefix<G>(carry, pr, j);
+                            const double acc = pr;  // the block's running sum up to this entry (cum_t): nothing to scan
                             const unsigned hit = (unsigned)((__ballot(in && acc > event) >> gshift) & GMASK);
                             if (hit) {
                                 const int f = __builtin_ctz(hit);
@@ -751,7 +750,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             }
                             const int n_in = min(G, b1 - b);
                             cnt += n_in;
-                            carry = gbcast<G>(acc, n_in - 1);
                         }
                         if (j == 0) {
                             if (found) {
