@@ -9,6 +9,8 @@ cfg = int(sys.argv[1])
 kw = dict(synthetic.BASELINE_CONFIGS[cfg])
 if cfg >= 3:
     kw["n_packets"] = 2_000_000
+if os.environ.get("N_PACKETS"):
+    kw["n_packets"] = int(os.environ["N_PACKETS"])
 prob = synthetic.make_problem(seed=1, **kw)
 for spec in sys.argv[2:]:
     eng = Engine(0)
