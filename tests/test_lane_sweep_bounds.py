@@ -1,0 +1,111 @@
+"""CPU checks of the two algebraic shortcuts the lane-sweep wave kernel relies on (tardis_amd/csrc/propagate_wave.hpp,
+tardis_amd/csrc/mc_device.hpp), in IEEE double arithmetic with the reference's operation order
+(trace_packet, modes/homologous_rad_packet_transport.py:100-156; update_line_estimators, estimators/radfield_estimator_calcs.py):
+
+* whenever the four cheap bounds of a line hold, the reference's own tests for that line come out negative (no boundary /
+  electron-scattering / line stop, no "nu difference" error) -- including inputs placed within a few ulps of every threshold;
+* the line-estimator term energy * (1 - (d_line + mu r) / (t c)) equals energy * nu_line / nu to rounding.
+"""
+import numpy as np
+
+C_LIGHT = 29979245800.0
+CLOSE_LINE_THRESHOLD = 1e-14
+
+
+def reference_line_outcome(nu_line, tau_line, tau_prev, nu, comov_nu, chi, tau_event, d_boundary, t_exp):
+    """0: the trace goes on; 1/2/3: boundary / electron / line stop; 4: MonteCarloException (one non-last line)."""
+    tau_incl = tau_prev + tau_line
+    d_cont = (tau_event - tau_prev) / chi
+    nu_diff = comov_nu - nu_line
+    q = nu_diff / nu
+    close = np.abs(q) < CLOSE_LINE_THRESHOLD
+    err = ~close & ~(nu_diff >= 0)
+    d_far = q * C_LIGHT * t_exp
+    d_trace = np.where(close, 0.0, d_far)
+    tau_combined = tau_incl + chi * d_trace
+    dmin = d_trace.copy()
+    dmin = np.where(d_boundary < dmin, d_boundary, dmin)
+    dmin = np.where(d_cont < dmin, d_cont, dmin)
+    stop_b = ~err & (d_trace != 0) & (dmin == d_boundary)
+    stop_e = ~err & (d_trace != 0) & ~stop_b & (dmin == d_cont)
+    stop_l = ~err & ~stop_b & ~stop_e & (tau_combined > tau_event)
+    return np.where(stop_b, 1, np.where(stop_e, 2, np.where(stop_l, 3, np.where(err, 4, 0))))
+
+
+def cheap_bounds_hold(nu_line, tau_line, tau_prev, nu, comov_nu, chi, tau_event, d_boundary, t_exp):
+    tc = t_exp * C_LIGHT
+    rcp_tc = 1.0 / tc
+    kp = ((chi * tc) / nu) * (1.0 + 2.0 ** -40)
+    xb = ((d_boundary * nu) * rcp_tc) * (1.0 - 2.0 ** -40)
+    X = comov_nu - nu_line
+    x = kp * X
+    D = tau_event - tau_prev
+    tau_n = tau_prev + tau_line
+    total = tau_n + x
+    return (X >= 0.0) & (X < xb) & (x < D) & (total <= tau_event)
+
+
+def _near(rng, n):
+    """factors 1 + delta with |delta| log-uniform between 1e-17 and 1e-6, both signs, and exact 1"""
+    d = 10.0 ** rng.uniform(-17, -6, n) * rng.choice([-1.0, 1.0], n)
+    d[rng.random(n) < 0.05] = 0.0
+    return 1.0 + d
+
+
+def test_cheap_bounds_imply_the_reference_goes_on():
+    rng = np.random.default_rng(2024)
+    n = 400_000
+    total_ok = 0
+    for kind in range(5):
+        t_exp = 10.0 ** rng.uniform(5.5, 7.0, n)
+        nu = 10.0 ** rng.uniform(14.0, 16.5, n)
+        dop = 1.0 - rng.uniform(-0.05, 0.05, n)
+        comov = nu * dop
+        chi = 10.0 ** rng.uniform(-17, -12, n)
+        d_boundary = 10.0 ** rng.uniform(12.0, 15.5, n)
+        tau_event = -np.log(rng.random(n))
+        tau_prev = tau_event * rng.uniform(0.0, 1.0, n) * (rng.random(n) < 0.7)
+        tau_line = 10.0 ** rng.uniform(-8, 1, n) * (rng.random(n) < 0.9)
+        tc = t_exp * C_LIGHT
+        if kind == 0:    # generic lines redward of the packet
+            X = d_boundary * nu / tc * rng.uniform(0.0, 1.5, n)
+        elif kind == 1:  # resonance within ulps of the shell boundary
+            X = d_boundary * nu / tc * _near(rng, n)
+        elif kind == 2:  # resonance within ulps of the electron-scattering distance
+            X = (tau_event - tau_prev) / chi * nu / tc * _near(rng, n)
+        elif kind == 3:  # tau_combined within ulps of tau_event
+            room = tau_event - (tau_prev + tau_line)
+            X = np.where(room > 0, room / chi * nu / tc * _near(rng, n), d_boundary * nu / tc * 0.3)
+        else:            # lines (almost) at the packet's comoving frequency, on either side
+            X = comov * 10.0 ** rng.uniform(-18, -12, n) * rng.choice([-1.0, 1.0], n)
+        nu_line = comov - X
+        args = (nu_line, tau_line, tau_prev, nu, comov, chi, tau_event, d_boundary, t_exp)
+        ok = cheap_bounds_hold(*args)
+        outcome = reference_line_outcome(*args)
+        assert not np.any(ok & (outcome != 0)), (kind, int(np.sum(ok & (outcome != 0))))
+        total_ok += int(ok.sum())
+    assert total_ok > 200_000    # (the bounds are not vacuous: most generic lines pass them)
+
+
+def test_line_estimator_term_is_energy_times_nu_line_over_nu():
+    rng = np.random.default_rng(7)
+    n = 1_000_000
+    t_exp = 10.0 ** rng.uniform(5.5, 7.0, n)
+    tc = t_exp * C_LIGHT
+    nu = 10.0 ** rng.uniform(14.0, 16.5, n)
+    energy = rng.uniform(0.5, 1.5, n) * 1e-7
+    r = 10.0 ** rng.uniform(14.0, 15.5, n)
+    mu = rng.uniform(-1.0, 1.0, n)
+    r = np.minimum(r, 0.3 * tc)                 # v < 0.3 c
+    dop = 1.0 - mu * (r / t_exp) / C_LIGHT       # partial relativity (frame_transformations.py:12-47)
+    comov = nu * dop
+    nu_line = comov * (1.0 - 10.0 ** rng.uniform(-16, -1.5, n) * (rng.random(n) < 0.98))
+    q = (comov - nu_line) / nu
+    d = np.where(np.abs(q) < CLOSE_LINE_THRESHOLD, 0.0, q * C_LIGHT * t_exp)
+    e_ref = energy * (1.0 - (d + mu * r) / tc)   # update_line_estimators
+    jb_ref = e_ref / nu
+    inv_nu = 1.0 / nu                            # the kernel's record: c_e = energy / nu, c_jb = c_e / nu
+    c_e = energy * inv_nu
+    c_jb = c_e * inv_nu
+    assert np.max(np.abs(c_e * nu_line / e_ref - 1.0)) < 5e-14
+    assert np.max(np.abs(c_jb * nu_line / jb_ref - 1.0)) < 5e-14
