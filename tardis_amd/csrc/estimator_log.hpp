@@ -6,17 +6,17 @@
 // atomic requests of a 1e7-packet launch leaving the L2 (TCC_EA0_ATOMIC == TCC_ATOMIC), and the chip sustains ~2e10 of
 // them per second -- that request rate, not arithmetic, bounded the propagation kernel (97 ms; 62 ms with the atomics
 // stubbed out).  A trace passes a CONTIGUOUS run of lines of one shell, and the value it adds to each of them is a pure
-// function of (line, packet state at the start of the trace).  So the propagation kernel only logs one 48-byte record
-// per trace, and three small kernels turn the log into the estimators:
+// function of (line, packet state at the start of the trace) -- in fact a per-trace constant times nu_line (see
+// LineVisitRecord in mc_device.hpp).  So the propagation kernel only logs one 24-byte record per trace, and three small
+// kernels turn the log into the estimators:
 //
 //   bin_count_kernel   -- histogram of the records over (shell, TILE-line tile) bins          (LDS histogram)
 //   bin_scatter_kernel -- counting sort of the record indices by bin                            (LDS ranks)
-//   accumulate_kernel  -- per bin slice: the tile's j_blue/Edotlu live in LDS, every record of the slice recomputes its
-//                         terms with the reference's arithmetic (same operation order as the sweep, so every term is
-//                         bit-identical to the one the atomics path adds) and adds them with LDS atomics; the tile is
-//                         then added to the global arrays once.
-// The sum order differs from the serial reference exactly as it does with atomics (floating-point sum of the same
-// terms in a different order).
+//   accumulate_kernel  -- per bin slice: the tile's j_blue/Edotlu live in LDS, every record of the slice adds its two
+//                         constants over its range of lines with LDS atomics; the tile is multiplied by nu_line and
+//                         added to the global arrays once.
+// The sums agree with the serial reference's to rounding: a different order of the same terms (as with atomics), each term
+// within ~1e-14 of the reference's (tests/test_lane_sweep_bounds.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -115,8 +115,7 @@ __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVi
                                                                     const unsigned *__restrict__ bin_start,
                                                                     const unsigned *__restrict__ slice_start, int n_bins,
                                                                     int tiles_per_shell, int n_lines, const double *__restrict__ nu_line,
-                                                                    double t_exp, double tc, double rcp_tc, double *__restrict__ jblue_t,
-                                                                    double *__restrict__ edot_t)
+                                                                    double *__restrict__ jblue_t, double *__restrict__ edot_t)
 {
     constexpr int TILE_LDS = EST_TILE + EST_APRON;
     __shared__ double tile_jb[TILE_LDS], tile_ed[TILE_LDS];

@@ -1150,12 +1150,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const unsigned acc_blocks = (unsigned)(cus * 2);
             if (full)
                 hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
-                                   slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
-                                   P.jblue_t, P.edot_t);
+                                   slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
             else
                 hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
-                                   slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.t_exp, P.tc, P.rcp_tc,
-                                   P.jblue_t, P.edot_t);
+                                   slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
             return hipGetLastError();
         };
         if (wave_kernel) {
