@@ -1147,7 +1147,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_start, bin_fill, slice_start);
             hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.region_count, lg.n_regions,
                                lg.region_capacity, n_bins, bin_fill, sorted);
-            const unsigned acc_blocks = (unsigned)(cus * 2);
+            const unsigned acc_blocks = (unsigned)(cus * 3);
             if (full)
                 hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
                                    slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
