@@ -8,6 +8,10 @@ import ctypes as C
 
 kw = dict(synthetic.BASELINE_CONFIGS[2])
 kw["n_packets"] = int(sys.argv[1])
+if os.environ.get("N_SHELLS"):
+    kw["n_shells"] = int(os.environ["N_SHELLS"])
+if os.environ.get("N_LINES"):
+    kw["n_lines"] = int(os.environ["N_LINES"])
 prob = synthetic.make_problem(seed=1, **kw)
 for spec in sys.argv[2:]:
     out = {}
