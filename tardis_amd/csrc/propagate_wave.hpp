@@ -61,7 +61,8 @@ struct __attribute__((aligned(16))) VpResult {
     double nu, energy, mu0;
     int used, visits, err, pad;
 };
-constexpr int VP_ROUND = 6;  // v-packets of one packet per round of a pooled volley (2 * VP_ROUND draws must fit the ring)
+constexpr int VP_ROUND = 6;  // v-packets of one packet per round of a pooled volley (5 and 8 were measured: no difference)
+static_assert(2 * VP_ROUND + 3 <= 16, "a round's mu and roulette draws, plus the 4 doubles of the refill that completes them, must fit WV_RING_VPK");
 
 // Kernel arguments.  Only what the sweep loop touches is passed by value (-> SGPRs); everything the event phase needs is
 // read through `cold` (a device copy) at the top of every pass, so that it does not occupy scalar registers -- and, once
