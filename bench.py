@@ -100,13 +100,19 @@ def main():
     eng.set_opacity(prob.opacity_state)
     eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
     eng.set_packets(prob.packet_collection)
-    distributed.setup_engine_comm(eng, pg)
+    rccl_ok = distributed.setup_engine_comm(eng, pg)
+    if not rccl_ok and pg.rank == 0:
+        print("warning: no RCCL communicator; the estimators are all-reduced on the host through gloo", file=sys.stderr)
 
     def step():
         eng.reset_estimators()
         eng.propagate()
         if n_gpus > 1:
-            eng.allreduce_estimators()
+            if rccl_ok:
+                eng.allreduce_estimators()
+            else:  # fallback: copy the estimator arrays out and reduce them through the control plane
+                r = eng.get_results(track_last_interaction=False)
+                pg.sum_arrays_([r.j_estimator, r.nu_bar_estimator, r.j_blue_estimator, r.edotlu_estimator])
 
     for _ in range(args.warmup):
         step()
@@ -143,7 +149,8 @@ def main():
                         f"{'off' if args.no_tracking else 'on'}; synthetic opacities (SURVEY 8d)",
             "packets_per_gpu": P, "n_shells": kw["n_shells"], "n_lines": kw["n_lines"],
             "line_interaction_type": kw["line_interaction_type"], "n_vpackets": kw.get("n_vpackets", 0),
-            "parallelism": f"packet-sharded x{n_gpus}, RCCL all-reduce of estimators per step" if n_gpus > 1 else "single GPU",
+            "parallelism": (f"packet-sharded x{n_gpus}, " + ("RCCL all-reduce of estimators per step" if rccl_ok
+                            else "host (gloo) all-reduce of estimators per step: RCCL communicator unavailable")) if n_gpus > 1 else "single GPU",
         },
     }
     if pg.rank == 0:

@@ -81,10 +81,25 @@ def shard_bounds(n_items: int, rank: int, world_size: int) -> tuple[int, int]:
     return (rank * n_items) // world_size, ((rank + 1) * n_items) // world_size
 
 
-def setup_engine_comm(engine, pg: ProcessGroup):
-    """Create the RCCL communicator of ``engine`` across the process group (no-op for one process)."""
+def setup_engine_comm(engine, pg: ProcessGroup) -> bool:
+    """Create the RCCL communicator of ``engine`` across the process group (no-op for one process).
+
+    Returns False -- on every rank -- if the communicator could not be created anywhere (librccl missing, init error); the
+    caller can then reduce the estimators through the control plane (``ProcessGroup.sum_arrays_``) instead of failing."""
     if not pg.is_distributed:
-        return
-    uid = engine.comm_unique_id() if pg.rank == 0 else None
+        return True
+    uid = None
+    if pg.rank == 0:
+        try:
+            uid = engine.comm_unique_id()
+        except Exception as exc:  # noqa: BLE001 -- reported, and agreed on by all ranks below
+            print(f"tardis_amd.distributed: no RCCL unique id ({exc})", flush=True)
     uid = pg.broadcast_bytes(uid, src=0)
-    engine.comm_init(pg.rank, pg.world_size, uid)
+    failed = 1.0 if uid is None else 0.0
+    if uid is not None:
+        try:
+            engine.comm_init(pg.rank, pg.world_size, uid)
+        except Exception as exc:  # noqa: BLE001
+            print(f"tardis_amd.distributed: rank {pg.rank}: RCCL communicator not created ({exc})", flush=True)
+            failed = 1.0
+    return pg.max_float(failed) == 0.0

@@ -32,6 +32,26 @@ def main():
     payload = pg.broadcast_bytes(b"x" * 128 if pg.rank == 0 else None, src=0)
     assert payload == b"x" * 128
     assert pg.max_float(float(pg.rank)) == 1.0
+
+    # communicator set-up: every rank learns the same verdict, whichever rank the failure happens on
+    class FakeEngine:
+        def __init__(self, fail_uid=False, fail_init_on=None):
+            self.fail_uid, self.fail_init_on, self.inited = fail_uid, fail_init_on, None
+
+        def comm_unique_id(self):
+            if self.fail_uid:
+                raise RuntimeError("no librccl")
+            return b"u" * 128
+
+        def comm_init(self, rank, world_size, uid):
+            if self.fail_init_on == rank:
+                raise RuntimeError("init failed")
+            self.inited = (rank, world_size, uid)
+
+    good = FakeEngine()
+    assert distributed.setup_engine_comm(good, pg) is True and good.inited == (pg.rank, 2, b"u" * 128)
+    assert distributed.setup_engine_comm(FakeEngine(fail_uid=True), pg) is False
+    assert distributed.setup_engine_comm(FakeEngine(fail_init_on=1), pg) is False
     pg.barrier()
     np.savez(out_path + f".rank{pg.rank}.npz", lo=lo, hi=hi, output_nus=pc.output_nus[lo:hi],
              output_energies=pc.output_energies[lo:hi], j=est[0], nu_bar=est[1], j_blue=est[2], edotlu=est[3])
