@@ -1028,7 +1028,17 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         const double log_per_packet = ctx->log_budget_per_packet;
         if (wave_kernel && ctx->log_capacity > 0)
             chunk = std::max<long long>(1 << 16, std::min<long long>(chunk, (long long)((double)ctx->log_capacity / log_per_packet)));
-        const bool two_streams = wave_kernel && chunk < ctx->n_packets && ctx->pipeline_chunks > 1;
+        // Several chunks (asked for, or forced by the log / state buffers): alternate them between two streams, so that the
+        // drain of one chunk's last, longest-lived packets overlaps the start of the next chunk (+9 % on the macroatom
+        // shape with two log-bounded chunks).  Needs a second set of chunk buffers: only if they fit comfortably.
+        bool two_streams = wave_kernel && chunk < ctx->n_packets && ctx->pipeline_chunks > 1;
+        if (wave_kernel && chunk < ctx->n_packets && ctx->pipeline_chunks == 1 && !ctx->stream2) {
+            size_t free_b = 0, total_b = 0;
+            const double extra = (double)chunk * ((double)mc::WV_STATE_STRIDE * sizeof(uint32_t) + sizeof(mc::LaunchRec) +
+                                                  log_per_packet * (sizeof(mc::LineVisitRecord) + 2.0 * sizeof(unsigned)));
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 2.0 * extra < 0.6 * (double)free_b) two_streams = true;
+        } else if (wave_kernel && chunk < ctx->n_packets && ctx->stream2)
+            two_streams = true;  // (the buffers of an earlier call are still there)
         if (two_streams && !ctx->stream2) {
             HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));

@@ -456,3 +456,27 @@ def test_negative_transition_probability_keeps_the_serial_walk(oracle, mode):
     for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
         assert got.counters[k] == ref.counters[k], k
     eng.close()
+
+
+@pytest.mark.gpu
+def test_log_bounded_chunks_alternate_between_two_streams(oracle):
+    """A call whose line-visit log does not fit log_capacity is split into chunks, which alternate between two streams (the
+    drain of one chunk overlaps the start of the next): same results as the oracle, several launches."""
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=29, n_packets=300_001, n_shells=6, n_lines=2_000, line_interaction_type="downbranch")
+    ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
+    eng = Engine(0)
+    eng.set_option("log_capacity", 1 << 23)      # 65536 packets per chunk at the initial budget of 128 traces per packet
+    eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+    for _ in range(2):
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        got = eng.get_results(track_last_interaction=True)
+        assert eng.last_kernel_times()["launches"] >= 4
+        assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+        assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+        assert_allclose(got.edotlu_estimator, ref.edotlu_estimator, rtol=EST_RTOL)
+        assert_allclose(got.j_estimator, ref.j_estimator, rtol=EST_RTOL)
+        for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
+            assert got.counters[k] == ref.counters[k], k
+    eng.close()
