@@ -25,7 +25,7 @@
 namespace mc {
 
 constexpr int EST_TILE = 2048;       // lines per LDS tile (2 x 16 KiB)
-constexpr int EST_SLICE = 8192;      // records per accumulate workgroup pass
+constexpr int EST_SLICE = 16384;     // records per accumulate workgroup pass
 constexpr int EST_APRON = 256;       // lines past the end of a tile that are still accumulated in LDS (traces start in
                                      // their bin's tile and may run on into the next one)
 constexpr int EST_MAX_BINS = 36864;  // largest LDS histogram of the binning kernels (dynamic LDS, 4 B per bin = 144 KiB)

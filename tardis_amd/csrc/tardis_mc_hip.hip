@@ -1151,7 +1151,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 e = hipFuncSetAttribute((const void *)mc::bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
                 if (e != hipSuccess) return e;
             }
-            const int bin_blocks = cus * 4;
+            const int bin_blocks = cus * 8;
             hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.region_count, lg.n_regions,
                                lg.region_capacity, n_bins, bin_count);
             hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_start, bin_fill, slice_start);
