@@ -6,18 +6,25 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one Monte Carlo iteration of the hot path over one resident batch of synthetic packets: zero the
-estimators, propagate every packet of this rank's shard (HIP kernels), and -- for N > 1 -- the one RCCL all-reduce
-of the estimator arrays (J, nu_bar, j_blue, Edotlu, v-hist) that an outer plasma iteration needs.  Inputs
-(packets, opacity tables) are resident in HBM before the timed region.  Weak scaling: every rank owns
-`--packets` packets, so an N-GPU iteration propagates N x packets.
+estimators, propagate every packet of this rank's shard (HIP kernels; one `tardis_mc_propagate` call, which splits the
+batch into log-bounded chunks on two streams), and -- for N > 1 -- the one RCCL all-reduce of the estimator arrays
+(J, nu_bar, j_blue, Edotlu, v-hist) that an outer plasma iteration needs.  Inputs (packets, opacity tables) are
+resident in HBM before the timed region.  Weak scaling: every rank owns `--packets` packets, so an N-GPU iteration
+propagates N x packets.
 
-Workload (N = 1): BASELINE.json configs[1] -- tardis_example shape, 1e7 packets, 20 shells, ~3e4 lines,
-downbranch, no v-packets, synthetic opacities (the reference's atomic data is not available offline).
+Workload (default, N = 1): BASELINE.json configs[2], the configuration the metric is quoted on -- full-Kurucz-sized
+line list (5e5 lines), macroatom line interaction, 20 shells, **1e8 packets per step**, no v-packets, last-interaction
+tracking on; synthetic opacities (the reference's atomic data is not available offline).  The packets are
+drawn by the device packet source (BlackBodySimpleSource.create_packets with NumPy's PCG64 streams
+reproduced by jump-ahead), so the host never builds the 4 GB of inputs; rank r draws packets [r P, (r+1) P) of the
+N P-packet stream.  `--config 2` selects configs[1] (tardis_example shape, 3e4 lines, downbranch, 1e7 packets).
 
-The JSON line carries `roofline` (algorithmic bytes of a step's propagation per launch / the HIP-event time of the
-dominant kernel -- the propagation kernel; the seeding kernel and the line-estimator passes of the step are reported
-beside it -- against the 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle -- the parity-pinned C port of the reference
-algorithm -- timed on this box's cores on a bounded sample of the same workload).
+The JSON line carries `roofline` (algorithmic bytes of the dominant kernel -- the propagation kernel -- per launch over
+its HIP-event time, against the 8 TB/s HBM peak; the whole step beside it), `cpu_baseline` (the CPU oracle -- the
+parity-pinned C port of the reference algorithm -- timed on this box's cores on a bounded sample of the same
+workload, with the GPU-vs-CPU parity of that sample) and `boundary` (one full drop-in call
+`transport.montecarlo_transport_with_vpackets` -- host arrays in, upload, set_opacity, propagate, results out -- on
+a bounded packet count: the PCIe-inclusive rate; never `value`).
 """
 from __future__ import annotations
 
@@ -34,9 +41,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from tardis_amd import distributed, spectrum, synthetic  # noqa: E402
+from tardis_amd import state as st  # noqa: E402
 from tardis_amd.engine import Engine  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+T_INNER = 1.0e4        # K, synthetic.make_problem's default photosphere temperature
 
 
 def algorithmic_bytes(c: dict, part: str = "step") -> float:
@@ -58,15 +67,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config number (2: 1e7 pkts downbranch 3e4 lines)")
+    ap.add_argument("--config", type=int, default=3,
+                    help="BASELINE.json config number (3 = configs[2]: 1e8 pkts macroatom 5e5 lines, the headline; "
+                         "2 = configs[1]: 1e7 pkts downbranch 3e4 lines)")
     ap.add_argument("--packets", type=int, default=None, help="packets per GPU per step (default: the config's)")
     ap.add_argument("--lines", type=int, default=None)
     ap.add_argument("--shells", type=int, default=None)
     ap.add_argument("--mode", type=str, default=None)
     ap.add_argument("--vpackets", type=int, default=None)
     ap.add_argument("--no-tracking", action="store_true", help="skip the last-interaction tracker outputs")
-    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="packets in the CPU-baseline sample (0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=None,
+                    help="packets in the CPU-baseline sample (0: skip; default sized for ~15 s of CPU work)")
+    ap.add_argument("--boundary-packets", type=int, default=None,
+                    help="packets of the drop-in boundary call timed after the steps (0: skip; default 1e7 capped by --packets)")
     ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="engine option (tardis_mc_set_option)")
     args = ap.parse_args()
 
     pg = distributed.init_from_env(backend="gloo")  # control plane only; the data-path collective is RCCL
@@ -88,18 +103,23 @@ def main():
         kw["n_vpackets"] = args.vpackets
     if args.config in (4, 5) and args.packets is None:
         kw["n_packets"] //= 8  # those configs quote the 8-GPU total
-    # every rank draws its own packet shard (iteration = rank changes the packet stream, not the opacities)
-    prob = synthetic.make_problem(seed=1, iteration=pg.rank, **kw)
-    P = prob.packet_collection.number_of_packets
+    P = int(kw.pop("n_packets"))
+    # opacities, geometry, configuration on the host (same on every rank); the packets never exist on the host
+    prob = synthetic.make_problem(seed=1, n_packets=1, **kw)
 
     eng = Engine(pg.local_rank)
     if args.variant is not None:
         eng.set_option("variant", args.variant)
+    for o in args.option:
+        name, _, val = o.partition("=")
+        eng.set_option(name, int(val))
     eng.set_option("track_last_interaction", 0 if args.no_tracking else 1)
     eng.set_geometry(prob.geometry, prob.time_explosion)
     eng.set_opacity(prob.opacity_state)
     eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
-    eng.set_packets(prob.packet_collection)
+    radius = float(prob.geometry.r_inner[0])
+    # rank r owns packets [r P, (r+1) P) of the job's N P-packet black-body draw (device packet source)
+    eng.create_blackbody_packets(P * n_gpus, radius, T_INNER, first=pg.rank * P, count=P)
     rccl_ok = distributed.setup_engine_comm(eng, pg)
     if not rccl_ok and pg.rank == 0:
         print("warning: no RCCL communicator; the estimators are all-reduced on the host through gloo", file=sys.stderr)
@@ -118,43 +138,40 @@ def main():
         step()
     eng.synchronize()
     pg.barrier()
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(None)  # read after the timed region (event queries would serialise the stream)
     eng.synchronize()
     pg.barrier()
     t1 = time.perf_counter()
     elapsed = pg.max_float(t1 - t0)
 
-    # kernel time of the last step (HIP events on the engine stream) and its work counters
+    # kernel time of the last step (HIP events on the engine's streams) and its work counters
     last_ms = eng.last_propagate_ms()
     ktimes = eng.last_kernel_times()
-    res = eng.get_results(track_last_interaction=False, want_line_estimators=False)
-    counters = res.counters
-    if n_gpus > 1:
-        pass  # counters are per rank; every rank runs the same-sized shard
+    counters = eng.last_counters()
 
     total_packets = float(P) * n_gpus * args.steps
     value = total_packets / elapsed
+    mode = kw["line_interaction_type"]
     out = {
         "metric": "packets/sec", "value": value, "unit": "packets/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[{args.config - 1}]: tardis_example shape, {P} packets/GPU/step, "
-                        f"{kw['n_shells']} shells, {kw['n_lines']} lines, {kw['line_interaction_type']}, "
+            "workload": f"BASELINE configs[{args.config - 1}]: {P} packets/GPU/step, "
+                        f"{kw['n_shells']} shells, {kw['n_lines']} lines, {mode}, "
                         f"{kw.get('n_vpackets', 0)} v-packets, last-interaction tracking "
-                        f"{'off' if args.no_tracking else 'on'}; synthetic opacities (SURVEY 8d)",
+                        f"{'off' if args.no_tracking else 'on'}; synthetic opacities (SURVEY 8d), packets from the "
+                        f"device black-body source (T_inner = {T_INNER:g} K)",
             "packets_per_gpu": P, "n_shells": kw["n_shells"], "n_lines": kw["n_lines"],
-            "line_interaction_type": kw["line_interaction_type"], "n_vpackets": kw.get("n_vpackets", 0),
+            "line_interaction_type": mode, "n_vpackets": kw.get("n_vpackets", 0),
             "parallelism": (f"packet-sharded x{n_gpus}, " + ("RCCL all-reduce of estimators per step" if rccl_ok
                             else "host (gloo) all-reduce of estimators per step: RCCL communicator unavailable")) if n_gpus > 1 else "single GPU",
         },
     }
     if pg.rank == 0:
-        # dominant kernel = the propagation kernel; its launches of one step are timed with HIP events on the engine stream
+        # dominant kernel = the propagation kernel; its launches of one step are timed with HIP events on the streams they run on
         launches = max(ktimes["launches"], 1)
         wave = args.variant in (None, 2, 3)
         dominant = "propagate_wave_kernel" if wave else ("propagate_lane_kernel" if args.variant == 0 else "propagate_group_kernel")
@@ -164,70 +181,114 @@ def main():
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         step_bytes = algorithmic_bytes(counters, "step")
         step_achieved = step_bytes / (last_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        default_workload = (args.config == 2 and args.packets is None and args.lines is None and args.shells is None
-                            and args.mode is None and args.vpackets is None and not args.no_tracking and args.variant is None)
-        if default_workload and os.path.exists(pmc_path):  # the PMC passes were collected on the default workload
-            try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = measured_traffic(args, P, launches)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel": f"{dominant} (dominant kernel of a step)", "kernel_ms": kernel_ms,
                            "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                           "note": "kernel_ms = mean HIP-event duration of the step's propagation launches; chunks alternate between two "
+                                   "streams and overlap, so launches x kernel_ms can exceed the step's device time",
                            "step": {"algorithmic_bytes": step_bytes, "device_ms": last_ms, "achieved": step_achieved,
                                     "frac": step_achieved / HBM_PEAK_GBS, "seed_kernel_ms": ktimes["seed_ms"],
                                     "estimator_passes_ms": ktimes.get("estimator_ms", 0.0),
-                                    "note": "all kernels of one iteration: MT19937 seeding, propagation, line-estimator passes"},
+                                    "note": "all kernels of one iteration: launch preparation, propagation, line-estimator passes"},
                            "per_packet": {k: counters[k] / max(P, 1) for k in ("line_visits", "events", "macro_transitions", "rng_draws")}}
-        if n_gpus == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(prob, eng, min(args.cpu_sample, P))
+        if n_gpus == 1:
+            n_cpu = args.cpu_sample if args.cpu_sample is not None else default_cpu_sample(kw)
+            if n_cpu > 0:
+                out["cpu_baseline"] = cpu_baseline(prob, eng, P, radius, min(n_cpu, P))
+            n_b = args.boundary_packets if args.boundary_packets is not None else min(P, 10_000_000)
+            if n_b > 0:
+                out["boundary"] = boundary_call(prob, eng, n_b, not args.no_tracking)
     if pg.rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
     pg.destroy()
 
 
-def cpu_baseline(prob, eng, n_sample: int) -> dict:
+def measured_traffic(args, P: int, launches: int):
+    """HBM bytes per launch of the propagation kernel from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes collected on this
+    workload (tools/gpu_profile.sh -> profiles/pmc_traffic_config<N>.json, corrected as MI355X_MICROARCH.md prescribes);
+    None when the file was collected on another workload."""
+    custom = any(v is not None for v in (args.lines, args.shells, args.mode, args.vpackets, args.variant)) or args.no_tracking or args.option
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_config{args.config}.json")
+    if custom or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        if int(d.get("packets_per_gpu", -1)) != P:
+            return None
+        return d.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def default_cpu_sample(kw: dict) -> int:
+    """~10-30 s of CPU work on a 16-thread box: the C oracle runs ~5e3 packets/s/thread on the 5e5-line macroatom shape
+    and ~2e5 on the tardis_example shape."""
+    heavy = kw["n_lines"] > 100_000 or kw["line_interaction_type"] == "macroatom" or kw.get("n_vpackets", 0) > 0
+    return 200_000 if heavy else 10_000_000
+
+
+def cpu_baseline(prob, eng, P: int, radius: float, n_sample: int) -> dict:
     """Time the CPU oracle (parity-pinned C port of the reference algorithm, OpenMP over packets) on the first
-    n_sample packets of the workload, and report the spectrum parity of the GPU result on that sample."""
+    n_sample packets of the workload, and report the parity of the GPU result on that sample."""
     from oracle import oracle
 
-    pc = prob.packet_collection
-    sub = pc.shard(0, max(pc.number_of_packets // n_sample, 1)) if n_sample < pc.number_of_packets else pc
+    # the first n_sample packets of the P-packet draw, regenerated by the device source and copied to the host
+    eng.create_blackbody_packets(P, radius, T_INNER, first=0, count=n_sample)
+    pk = eng.get_packets()
+    l_bb = 4 * np.pi * st.SIGMA_SB * radius**2 * T_INNER**4
+    sub = st.PacketCollection(pk["initial_radii"], pk["initial_nus"], pk["initial_mus"], pk["initial_energies"],
+                              pk["packet_seeds"], l_bb)
     n = sub.number_of_packets
     threads = oracle.max_threads()
-    args = (sub, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
-            prob.spectrum_frequency_grid)
+    a = (prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration, prob.spectrum_frequency_grid)
     t0 = time.perf_counter()
-    ref = oracle.run(*args, math_mode=oracle.MATH_PORTABLE, n_threads=threads, track_last_interaction=False)
+    ref = oracle.run(sub, *a, math_mode=oracle.MATH_PORTABLE, n_threads=threads, track_last_interaction=False)
     dt_all = time.perf_counter() - t0
     n1 = max(n // 8, 1)
     sub1 = sub.shard(0, max(n // n1, 1))
     t0 = time.perf_counter()
-    oracle.run(sub1, *args[1:], math_mode=oracle.MATH_PORTABLE, n_threads=1, track_last_interaction=False)
+    oracle.run(sub1, *a, math_mode=oracle.MATH_PORTABLE, n_threads=1, track_last_interaction=False)
     dt_1 = time.perf_counter() - t0
     # GPU result on the same sample (per-packet results do not depend on batching)
-    eng.set_packets(sub)
     eng.reset_estimators()
     eng.propagate()
     eng.synchronize()
     got = eng.get_results(track_last_interaction=False, want_line_estimators=False)
-    a = spectrum.emitted_luminosity_histogram(got.output_nus, got.output_energies, pc.time_of_simulation, prob.spectrum_frequency_grid)
-    b = spectrum.emitted_luminosity_histogram(ref.output_nus, ref.output_energies, pc.time_of_simulation, prob.spectrum_frequency_grid)
+    t_sim = sub.time_of_simulation
+    ha = spectrum.emitted_luminosity_histogram(got.output_nus, got.output_energies, t_sim, prob.spectrum_frequency_grid)
+    hb = spectrum.emitted_luminosity_histogram(ref.output_nus, ref.output_energies, t_sim, prob.spectrum_frequency_grid)
     return {
         "value": n / dt_all, "unit": "packets/s", "cores": threads, "kind": "port",
         "sample": f"first {n} packets of the workload, CPU oracle (C port of the reference algorithm, -O2 IEEE-strict, "
                   f"OpenMP {threads} threads) {dt_all:.1f} s; 1 thread on {sub1.number_of_packets} packets: "
                   f"{sub1.number_of_packets / dt_1:.0f} packets/s",
         "single_thread_value": sub1.number_of_packets / dt_1,
-        "spectrum_rel_l2_gpu_vs_cpu": spectrum.relative_l2(a, b),
+        "spectrum_rel_l2_gpu_vs_cpu": spectrum.relative_l2(ha, hb),
         "per_packet_bit_exact": bool(np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)),
         "max_rel_diff_J": float(np.max(np.abs(got.j_estimator - ref.j_estimator) / np.abs(ref.j_estimator))),
         "max_rel_diff_nu_bar": float(np.max(np.abs(got.nu_bar_estimator - ref.nu_bar_estimator) / np.abs(ref.nu_bar_estimator))),
     }
+
+
+def boundary_call(prob, eng, n: int, track: bool) -> dict:
+    """One full drop-in call through the Python boundary on host arrays: marshalling, H2D of the packets and of the
+    opacity state (transposes, running sums), propagation, D2H of the per-packet outputs, trackers and estimators."""
+    from tardis_amd import transport
+
+    pc = synthetic.black_body_packets(n, float(prob.geometry.r_inner[0]), T_INNER)
+    trackers = st.LastInteractionTrackers(n) if track else None
+    cfg = prob.montecarlo_configuration
+    t0 = time.perf_counter()
+    transport.montecarlo_transport_with_vpackets(pc, prob.geometry, prob.time_explosion, prob.opacity_state, cfg,
+                                                 prob.spectrum_frequency_grid, trackers, cfg.NUMBER_OF_VPACKETS, False, None,
+                                                 engine=eng)
+    dt = time.perf_counter() - t0
+    return {"packets": n, "ms": 1e3 * dt, "packets_per_s": n / dt, "device_ms": transport.montecarlo_transport_with_vpackets.last_kernel_ms,
+            "note": "transport.montecarlo_transport_with_vpackets on host arrays (upload, set_opacity, propagate, get_results incl. "
+                    "last-interaction trackers and [L,S] estimators); PCIe-inclusive, not `value`"}
 
 
 if __name__ == "__main__":

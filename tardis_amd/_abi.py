@@ -150,6 +150,10 @@ def marshal_opacity(op) -> Marshalled:
     L, S = tau.shape
     if len(nu) != L or len(ne) != S:
         raise ValueError("tau_sobolev must be [n_lines, n_shells]")
+    if prob.ndim == 2 and prob.shape == (1, 1) and S > 1 and len(edge) <= 1 and len(ttype) <= 1:
+        # line_interaction_type "scatter": OpacityState.to_numba passes np.zeros((1, 1)) and size-1 macro tables
+        # (tardis/opacities/opacity_state.py:199-209); the engine wants one column per shell
+        prob = np.zeros((1, S))
     T = prob.shape[0]
     if prob.ndim != 2 or prob.shape[1] != S:
         raise ValueError("transition_probabilities must be [n_transitions, n_shells]")

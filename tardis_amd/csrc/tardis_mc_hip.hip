@@ -118,6 +118,7 @@ struct TardisMcContext {
     // v-packet log
     DevBuf vlog_count, vlog_packet, vlog_seq, vlog_nu, vlog_energy, vlog_mu, vlog_r;
     long long vlog_capacity = 0;
+    bool vlog_capacity_user = false;  // set through the vpacket_log_capacity option (otherwise sized per propagate call)
     // scratch
     DevBuf rng_state, counters, first_error, next_packet, seeded_states, problem_dev;
     mc::DeviceProblem problem_host{};
@@ -135,7 +136,8 @@ struct TardisMcContext {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], seeded_states2, next_packet2, wave_cold_dev;
-    DevBuf seed_chk[2], vp_scratch;  // wave kernel: word 397 of every packet's init_genrand sequence (lazy MT19937 seeding)
+    DevBuf seed_chk[2], vp_scratch[2];  // (vp_scratch: per buffer set -- chunks on the two streams overlap)
+    // wave kernel: word 397 of every packet's init_genrand sequence (lazy MT19937 seeding)
     int pipeline_chunks = 1;  // >1: split a propagate call of the wave kernel into chunks on two streams (measured: a loss -- every chunk pays the drain of its last packets)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
     double traces_per_packet = 0.0;  // measured by the last propagate (sizes the line-visit log of the next one)
@@ -186,6 +188,23 @@ __global__ void transpose_kernel(const double *__restrict__ in, double *__restri
     }
 }
 
+// Stores a launch-argument block into device memory.  The value travels in the kernel's argument buffer, which the runtime
+// copies when the launch is enqueued -- unlike hipMemcpyAsync from pageable host memory, nothing on the host has to stay
+// alive or unchanged afterwards, so back-to-back propagate calls need no stream synchronisation between them.
+template <typename T>
+__global__ void store_value_kernel(T *dst, const T v)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+template <typename T>
+hipError_t store_value(hipStream_t st, T *dst, const T &v)
+{
+    static_assert(sizeof(T) <= 3584, "argument block too large for the kernel-argument buffer");
+    hipLaunchKernelGGL(store_value_kernel<T>, dim3(1), dim3(64), 0, st, dst, v);
+    return hipGetLastError();
+}
+struct FirstErrorInit { long long v[2]; };
+
 // sum private copies into copy 0 (in place)
 __global__ void reduce_copies_kernel(double *base, long long n, long long stride, int copies)
 {
@@ -230,7 +249,9 @@ __global__ void debug_eval_kernel(int op, const double *x, const double *y, doub
 // ---- micro-benchmarks of the memory system (design input; not part of the product path)
 // which: 0 random fp64 atomic add, agent scope; 1 same, workgroup scope inside a per-XCD private slice;
 //        2 fp64 atomic add, 16 consecutive doubles per 16-lane group, agent scope; 3 same, workgroup scope/XCD slice;
-//        4 random 8-byte loads; 5 16-lane-coalesced 8-byte loads
+//        4 random 8-byte loads; 5 16-lane-coalesced 8-byte loads;
+//        6..9 every lane reads its own random, naturally aligned block of 16 / 32 / 64 / 128 bytes (dwordx4 loads);
+//        10 dependent chain: the address of a lane's next random 8-byte load comes out of the loaded value (latency)
 __global__ void microbench_kernel(int which, double *table, long long n, int iters, double *sink)
 {
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -240,6 +261,27 @@ __global__ void microbench_kernel(int which, double *table, long long n, int ite
     long long span = n, base0 = 0;
     if (xcd_slice) { span = n / 8; base0 = span * (mc::xcc_id() & 7); }
     double acc = 0.0;
+    if (which >= 6 && which <= 9) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const int quads = 1 << (which - 6);  // 16-byte pieces per block
+        const unsigned long long n_blocks = (unsigned long long)n / (2ull * quads);
+        for (int it = 0; it < iters; ++it) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            const v2d *b = reinterpret_cast<const v2d *>(table) + ((st >> 20) % n_blocks) * quads;
+            v2d v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q < quads) v[q] = b[q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q < quads) acc += v[q].x + v[q].y;
+        }
+    } else if (which == 10) {
+        unsigned long long r = st >> 20;
+        for (int it = 0; it < iters; ++it) {
+            const double v = table[(long long)(r % (unsigned long long)span)];
+            r = r * 6364136223846793005ull + 1442695040888963407ull + (unsigned long long)__double_as_longlong(v);
+            acc += v;
+        }
+    } else
     for (int it = 0; it < iters; ++it) {
         st = st * 6364136223846793005ull + 1442695040888963407ull;
         unsigned long long r = st >> 20;
@@ -516,7 +558,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
         ctx->log_sorted[b].release();
     }
     ctx->seeded_states2.release(); ctx->next_packet2.release(); ctx->wave_cold_dev.release();
-    ctx->seed_chk[0].release(); ctx->seed_chk[1].release(); ctx->vp_scratch.release();
+    ctx->seed_chk[0].release(); ctx->seed_chk[1].release(); ctx->vp_scratch[0].release(); ctx->vp_scratch[1].release();
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
@@ -541,7 +583,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "blocks_per_cu") ctx->blocks_per_cu = std::max(1, (int)value);
     else if (n == "track_last_interaction") ctx->track = value != 0;
     else if (n == "estimator_copies") { ctx->est_copies = std::max(1, std::min(8, (int)value)); ctx->est_valid = false; }
-    else if (n == "vpacket_log_capacity") ctx->vlog_capacity = value;
+    else if (n == "vpacket_log_capacity") { ctx->vlog_capacity = value; ctx->vlog_capacity_user = value > 0; }
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
     else if (n == "lane_sweep_min_active") ctx->ls_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
@@ -963,7 +1005,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     const bool vpk = c.number_of_vpackets > 0;
     // v-packet log buffers
     if (c.enable_vpacket_tracking && vpk) {
-        if (ctx->vlog_capacity <= 0) ctx->vlog_capacity = std::max<long long>(1024, ctx->n_packets * c.number_of_vpackets * 64);
+        // (sized for the current call: the engine is cached per process, a later, larger run must not inherit a smaller log)
+        if (!ctx->vlog_capacity_user) ctx->vlog_capacity = std::max<long long>(1024, ctx->n_packets * c.number_of_vpackets * 64);
         size_t cap = (size_t)ctx->vlog_capacity;
         HIP_TRY(ctx, ctx->vlog_count.ensure(sizeof(unsigned long long)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->vlog_count.p, 0, sizeof(unsigned long long), ctx->stream));
@@ -976,11 +1019,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     }
     const int cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
     HIP_TRY(ctx, ctx->first_error.ensure(2 * sizeof(long long)));
-    const long long init_err[2] = {0x7fffffffffffffffLL, 0};
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->first_error.p, init_err, sizeof init_err, hipMemcpyHostToDevice, ctx->stream));
+    // (argument blocks reach the device through store_value(): consecutive propagate calls -- iterations, chunks submitted by
+    // the host -- are not serialised by a stream synchronisation here)
+    HIP_TRY(ctx, store_value(ctx->stream, ctx->first_error.as<FirstErrorInit>(), FirstErrorInit{{0x7fffffffffffffffLL, 0}}));
     HIP_TRY(ctx, ctx->next_packet.ensure(sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // init_err lives on this stack frame
     // the cooperative kernel relies on a sorted line list (bucket index, monotone stopping predicate); anything else --
     // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
     // automatic choice: the wave-owner kernel (its pooled v-packet volleys take up to 32 v-packets per volley: one bit of
@@ -1052,7 +1095,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         ctx->problem_host = make_device_problem(ctx);
         const mc::DeviceProblem &F = ctx->problem_host;
         HIP_TRY(ctx, ctx->problem_dev.ensure(sizeof(mc::DeviceProblem)));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->problem_dev.p, &ctx->problem_host, sizeof(mc::DeviceProblem), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, store_value(ctx->stream, ctx->problem_dev.as<mc::DeviceProblem>(), ctx->problem_host));
         mc::GroupArgs P{};
         P.cold = ctx->problem_dev.as<mc::DeviceProblem>();
         P.n_shells = F.n_shells; P.n_lines = F.n_lines; P.n_trans = F.n_trans;
@@ -1225,10 +1268,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 wc.P = P; wc.P.next_packet = next_packet; wc.D = F; wc.log = lg; wc.seeded_states = seeded;
                 wc.chunk_first = first; wc.chunk_count = count;
                 wc.launch = ctx->seed_chk[b].as<mc::LaunchRec>();
-                if (vpk) HIP_TRY(ctx, ctx->vp_scratch.ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(mc::VpResult)));
-                wc.vp_scratch = ctx->vp_scratch.as<mc::VpResult>();
+                if (vpk) HIP_TRY(ctx, ctx->vp_scratch[b].ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(mc::VpResult)));
+                wc.vp_scratch = ctx->vp_scratch[b].as<mc::VpResult>();
                 mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci;
-                HIP_TRY(ctx, hipMemcpyAsync(wc_dev, &wc, sizeof(mc::WaveCold), hipMemcpyHostToDevice, st));
+                HIP_TRY(ctx, store_value(st, wc_dev, wc));
                 mc::WaveHot hot{};
                 hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
                 hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
@@ -1329,6 +1372,7 @@ int tardis_mc_last_counters(TardisMcContext *ctx, int64_t out_counters[TARDIS_MC
     HIP_TRY(ctx, hipMemcpyAsync(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < TARDIS_MC_N_COUNTERS; ++k) out_counters[k] = (int64_t)cnt[k];
+    out_counters[TARDIS_MC_CNT_PACKETS] = ctx->n_packets;
     return TARDIS_MC_OK;
 }
 
@@ -1452,12 +1496,14 @@ int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const Ta
     if ((rc = tardis_mc_set_geometry(ctx, geometry))) return rc;
     if ((rc = tardis_mc_set_opacity(ctx, opacity))) return rc;
     if ((rc = tardis_mc_set_config(ctx, config))) return rc;
-    if (result && result->vpacket_log_capacity > 0) ctx->vlog_capacity = result->vpacket_log_capacity;
+    if (result && result->vpacket_log_capacity > 0) { ctx->vlog_capacity = result->vpacket_log_capacity; ctx->vlog_capacity_user = true; }
     if ((rc = tardis_mc_set_packets(ctx, packets))) return rc;
     if ((rc = tardis_mc_reset_estimators(ctx))) return rc;
     if ((rc = tardis_mc_propagate(ctx))) return rc;
     if ((rc = tardis_mc_synchronize(ctx))) return rc;
-    return tardis_mc_get_results(ctx, result);
+    rc = tardis_mc_get_results(ctx, result);
+    ctx->vlog_capacity_user = false;  // (the caller's capacity was for this call only)
+    return rc;
 }
 
 int tardis_mc_packet_spectrum(TardisMcContext *ctx, double time_of_simulation, double luminosity_nu_start,

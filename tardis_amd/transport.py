@@ -32,14 +32,24 @@ def get_engine(device_id: int | None = None) -> Engine:
 
 
 def _fill_trackers(trackers, soa: st.LastInteractionTrackers):
-    """Accept the reference's list of per-packet TrackerLastInteraction objects and fill them in place."""
+    """Accept the reference's list of per-packet TrackerLastInteraction objects and fill them in place
+    (fields of packets/trackers/tracker_last_interaction.py:8-254)."""
     if trackers is None or isinstance(trackers, st.LastInteractionTrackers):
         return
     names = st.LastInteractionTrackers.F64_FIELDS + st.LastInteractionTrackers.I64_FIELDS
-    cols = {n: getattr(soa, n) for n in names}
+    if len(trackers) != len(soa):
+        raise ValueError(f"{len(trackers)} trackers for {len(soa)} packets")
+    if len(trackers):
+        # enable_rpacket_tracking makes run_classic pass TrackerFull objects (array-valued fields, one row per event,
+        # packets/trackers/tracker_full.py): the engine records the last interaction only
+        first = trackers[0]
+        if type(first).__name__ == "TrackerFull" or any(np.ndim(getattr(first, n, 0.0)) != 0 for n in names):
+            raise NotImplementedError("full r-packet tracking (TrackerFull, montecarlo.tracking.track_rpacket) is not "
+                                      "implemented by the HIP engine; only TrackerLastInteraction is")
+    cols = {n: getattr(soa, n).tolist() for n in names}
     for i, t in enumerate(trackers):
         for n in names:
-            setattr(t, n, cols[n][i].item())
+            setattr(t, n, cols[n][i])
 
 
 def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, time_explosion: float,
@@ -65,12 +75,25 @@ def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, 
     track = trackers is not None
     eng.set_option("track_last_interaction", int(track))
     eng.set_packets(packet_collection)
-    eng.reset_estimators()
-    eng.propagate()
-    eng.synchronize()
     out_nus, out_en = packet_collection.output_nus, packet_collection.output_energies
     in_place = all(isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous for a in (out_nus, out_en))
-    res = eng.get_results(out_nus if in_place else None, out_en if in_place else None, track_last_interaction=track)
+    vlog_capacity = None
+    for _attempt in range(2):
+        eng.reset_estimators()
+        eng.propagate()
+        eng.synchronize()
+        res = eng.get_results(out_nus if in_place else None, out_en if in_place else None, track_last_interaction=track,
+                              vpacket_log_capacity=vlog_capacity)
+        if res.vpacket_log_count <= len(res.vpacket_nus):
+            break
+        # The v-packet log was sized from a guess and overflowed (the device then drops entries): the run is
+        # deterministic, so repeat it with the capacity it asked for -- the reference returns every v-packet.
+        vlog_capacity = res.vpacket_log_count
+        eng.set_option("vpacket_log_capacity", vlog_capacity)
+    else:
+        raise RuntimeError("v-packet log overflow persisted after resizing")
+    if vlog_capacity is not None:
+        eng.set_option("vpacket_log_capacity", 0)  # back to automatic sizing
     if not in_place:
         packet_collection.output_nus[:] = res.output_nus
         packet_collection.output_energies[:] = res.output_energies
