@@ -12,7 +12,8 @@ import subprocess
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtardis_mc_hip.so")
+# (TARDIS_MC_LIB: a profiling build of the same sources, e.g. with -DTMC_SECTION_TIMERS; tools/ only)
+LIB_PATH = os.environ.get("TARDIS_MC_LIB") or os.path.join(_HERE, "libtardis_mc_hip.so")
 _lib = None
 
 # every symbol include/tardis_mc.h declares: name -> (restype, argtypes)

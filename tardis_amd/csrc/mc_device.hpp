@@ -54,6 +54,9 @@ struct DeviceProblem {
     double *li_radius, *li_nu, *li_energy, *li_before_nu, *li_before_mu, *li_before_energy, *li_after_nu,
         *li_after_mu, *li_after_energy;
     long long *li_shell_id, *li_interaction_type, *li_line_absorb_id, *li_line_emit_id, *li_interactions_count;
+    // wave kernel: one 64-byte record per packet, rewritten at every interaction (TrackerRecord, propagate_wave.hpp) and
+    // unpacked into the arrays above once the propagation is over -- one write request per interaction instead of nine
+    uint4 *li_rec;
     // geometry
     int n_shells;
     const double *r_inner, *r_outer;
@@ -115,6 +118,11 @@ struct GroupArgs {
     // up to and including t (same additions in the same order, so the jump search compares the very numbers the
     // reference's loop does); trans_nu[t] = nu of the line transition t emits (0 for internal transitions)
     const double *cum_t, *trans_nu;
+    // compact tables of the per-lane macro-atom walk (walk_tables.hpp; null unless the launch uses them)
+    const unsigned short *cum16;  // [S][cum16_stride]
+    const uint2 *rec8;            // [compact transitions]
+    const int2 *quad_info;        // [compact transitions / 8]
+    unsigned cum16_stride;
     double *jblue_t, *edot_t;
     long long est_copy_stride;
     unsigned long long *next_packet;

@@ -24,6 +24,7 @@
 #include "mc_device.hpp"
 #include "propagate_group.hpp"
 #include "estimator_log.hpp"
+#include "walk_tables.hpp"
 
 namespace mc {
 
@@ -231,6 +232,36 @@ __global__ void __launch_bounds__(256) macro_cumulative_kernel(const double *__r
         c[k] = carry;
     }
     if (neg) atomicOr(negative, 1);
+}
+
+// Last-interaction tracker (packets/trackers/tracker_last_interaction.py:8-254) as the wave kernel keeps it: one 64-byte record
+// per packet, rewritten at every interaction with four 16-byte stores (one write request; nine 8-byte stores into nine
+// arrays were nine requests, a quarter of all memory requests of the macroatom workload) and unpacked into the boundary's
+// arrays by tracker_unpack_kernel after the propagation.  The fields the reference fills at the end of a packet (nu, energy,
+// after_nu, after_energy) equal the packet's outputs.
+struct __attribute__((aligned(16))) TrackerRecord {
+    double before_nu, before_mu, before_energy, radius, after_mu;
+    int shell, type, absorb, emit, count, valid;
+};
+static_assert(sizeof(TrackerRecord) == 64, "TrackerRecord is one 64-byte request");
+
+__global__ void __launch_bounds__(256) tracker_unpack_kernel(DeviceProblem D, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double e = D.out_e[i];
+    if (e == -99.0) return;  // the packet ended with an error: its tracker fields stay as they were
+    const TrackerRecord r = reinterpret_cast<const TrackerRecord *>(D.li_rec)[i];
+    const bool any = r.valid != 0 && r.count > 0;
+    const double nan = __builtin_nan("");
+    const double nu = D.out_nu[i], en = fabs(e);
+    D.li_radius[i] = any ? r.radius : nan;
+    D.li_nu[i] = any ? nu : nan; D.li_energy[i] = any ? en : nan;
+    D.li_before_nu[i] = any ? r.before_nu : nan; D.li_before_mu[i] = any ? r.before_mu : nan; D.li_before_energy[i] = any ? r.before_energy : nan;
+    D.li_after_nu[i] = any ? nu : nan; D.li_after_mu[i] = any ? r.after_mu : nan; D.li_after_energy[i] = any ? en : nan;
+    D.li_shell_id[i] = any ? r.shell : -1; D.li_interaction_type[i] = any ? r.type : -1;
+    D.li_line_absorb_id[i] = any ? r.absorb : -1; D.li_line_emit_id[i] = any ? r.emit : -1;
+    D.li_interactions_count[i] = any ? r.count : 0;
 }
 
 // What a lane needs to start a packet, prepared by launch_prep_kernel for the whole chunk (one record per packet, 48 bytes): the
@@ -644,13 +675,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             } else {
                 interacted = true;
                 if (TRACK) {
-                    // the tracker's record of the (so far) last interaction goes straight to the output arrays: the stores
-                    // are not waited for, and nothing of it has to stay in registers until the packet ends
-                    const DeviceProblem *C = &W->D;
-                    const long long i = chunk_first + pkt;
-                    C->li_before_nu[i] = p.nu; C->li_before_mu[i] = p.mu; C->li_before_energy[i] = p.energy;
-                    C->li_line_absorb_id[i] = (type == IT_LINE) ? p.next_line_id : -1;
-                    C->li_radius[i] = p.r; C->li_shell_id[i] = p.shell; C->li_interaction_type[i] = type;
+                    // the packet before the interaction, parked in LDS (free between the sweeps) until the record is
+                    // written once the interaction is complete: nothing of it occupies registers during the macro-atom walk
+                    sh.nu[lane] = p.nu; sh.rcp_nu[lane] = p.mu; sh.comov_nu[lane] = p.energy;
                 }
                 // common part of line_scatter_event (interaction_event_callers.py:187-239) and thomson_scatter
                 // (interaction_events.py:184-217): Doppler with the old angle, new isotropic angle, Doppler back
@@ -677,7 +704,76 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         // the block's probabilities up until the sum exceeds the drawn number; the sums are precomputed (cum_t, same
         // additions in the same order), so the jump is the first entry of the block's monotone run that exceeds it:
         // the first eight entries in one round trip (the short blocks of downbranch end there), then a 4-ary search.
-        if (P.line_interaction_type == 2 && !(P.debug_flags & 128)) {  // (flag 128: the per-lane search below, for tests)
+        if (P.cum16) {
+            // macroatom mode, the default: every lane walks for its own packet on the compact tables (walk_tables.hpp) -- per
+            // jump one 16..64-byte read of the block's 16-bit running sums (all of a block of <= 32 transitions; longer blocks
+            // are first narrowed by a binary search over their 8-entry quads) and one 8-byte read of what the selected
+            // transition leads to.  64 jumps of a wave are in flight at once; here mb0 / mb1 = compact start / rows of the block.
+            for (;;) {
+                if (!__ballot(in_macro)) break;
+                refill(__ballot(in_macro && r_cnt < 1), seeded_states);
+                double event = 0.0;
+                unsigned x = 0;
+                int q_lo = 0, q_hi = 0;
+                const unsigned short *__restrict__ blk = P.cum16 + ((size_t)p.shell * P.cum16_stride + (unsigned)mb0);
+                if (in_macro) {
+                    event = draw();
+                    x = (unsigned)(event * 65536.0);  // floor: event is in [0, 1)
+                    q_hi = (mb1 + 7) >> 3;
+                }
+                // blocks of more than 32 transitions: first quad whose last entry is not below x (entries are monotone)
+                while (__ballot(in_macro && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1)) {
+                    if (in_macro && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1) {
+                        const int qm = q_lo + ((q_hi - q_lo) >> 1);
+                        const unsigned v = blk[8 * qm + 7];
+                        if (v < x) q_lo = qm + 1; else q_hi = qm;
+                    }
+                }
+                int sel = -1;  // position of the selected transition in its block; -1: the block ran out
+                if (in_macro) {
+                    const int n_quads = (mb1 + 7) >> 3;
+                    const int nq = min(WALK_WINDOW_QUADS, n_quads - q_lo);
+                    const uint4 *__restrict__ wp = reinterpret_cast<const uint4 *>(blk + 8 * q_lo);
+                    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+                    if (nq > 0) w0 = wp[0];
+                    if (nq > 1) w1 = wp[1];
+                    if (nq > 2) w2 = wp[2];
+                    if (nq > 3) w3 = wp[3];
+                    const unsigned xx = x | (x << 16);
+                    unsigned less = 0, gt = 0;
+                    if (nq > 0) walk_count_quad(w0, xx, less, gt);
+                    if (nq > 1) walk_count_quad(w1, xx, less, gt);
+                    if (nq > 2) walk_count_quad(w2, xx, less, gt);
+                    if (nq > 3) walk_count_quad(w3, xx, less, gt);
+                    const int n_less = (int)((less & 0xffffu) + (less >> 16)), n_gt = (int)((gt & 0xffffu) + (gt >> 16));
+                    int k = 8 * q_lo + n_less;  // every entry before it is surely <= the number drawn
+                    if (8 * nq - n_gt - n_less > 0) {
+                        // entries equal to x (2^-16 of the draws per entry; the 0xffff padding when x = 65535): the reference's
+                        // own comparison on the fp64 running sums, in order
+                        const double *__restrict__ cum = P.cum_t + (size_t)p.shell * (size_t)P.n_trans;
+                        for (; k < mb1; ++k) {
+                            const unsigned v = blk[k];
+                            if (v > x) break;
+                            const int2 qi = P.quad_info[(unsigned)(mb0 + k) >> 3];
+                            if (cum[(unsigned)(qi.x + (k & 7))] > event) break;
+                        }
+                    }
+                    if (k < mb1) sel = k;
+                    macro += (unsigned)(sel >= 0 ? sel + 1 : mb1);
+                }
+                if (in_macro) {
+                    if (sel < 0) { err = ERR_MACRO_ATOM; in_macro = false; }
+                    else {
+                        const uint2 rec = P.rec8[(unsigned)(mb0 + sel)];
+                        if (rec.y & WALK_EMIT) {
+                            emit = (int)rec.x;
+                            in_macro = false;
+                            if (rec.y & WALK_UNSUPPORTED) err = ERR_UNSUPPORTED;
+                        } else { mb0 = (int)rec.x; mb1 = (int)rec.y; }
+                    }
+                }
+            }
+        } else if (P.line_interaction_type == 2 && !(P.debug_flags & 128)) {  // (flag 128: the per-lane search below, for tests)
             // macroatom mode (long chains of jumps, and a wave waits for its longest chain: one coalesced round trip per jump): the wave's G-lane groups scan the blocks, G
             // probabilities per coalesced load, accumulated in the reference's serial order (macro_atom_group() of the
             // group kernel).  The work items and results live in LDS that the trace parameters do not need right now.
@@ -829,6 +925,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         if (ready) {
             if (interacted && !err) {
                 int emit_id = -1;
+                const int absorb_id = (type == IT_LINE) ? p.next_line_id : -1;  // (the line that absorbed the packet)
                 if (type == IT_LINE) {  // line_emission (interaction_events.py:227-258); its inverse Doppler factor == inv_new
                     p.nu = (have_emit_nu ? emit_nu : P.nu_line[emit]) * inv_new;
                     p.next_line_id = emit + 1;
@@ -836,13 +933,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 }
                 if (FULL) p.mu = aberration_cmf_to_lf(p.r, t, p.mu);
                 if (TRACK) {
-                    const DeviceProblem *C = &W->D;
-                    const long long i = chunk_first + pkt;
-                    C->li_line_emit_id[i] = emit_id;
-                    C->li_after_mu[i] = p.mu;
                     trk_count += 1 + trk_boundary;
                     trk_boundary = 0;
                     trk_any = true;
+                    TrackerRecord rec;
+                    rec.before_nu = sh.nu[lane]; rec.before_mu = sh.rcp_nu[lane]; rec.before_energy = sh.comov_nu[lane];
+                    rec.radius = p.r; rec.after_mu = p.mu;
+                    rec.shell = p.shell; rec.type = type; rec.absorb = absorb_id; rec.emit = emit_id;
+                    rec.count = trk_count; rec.valid = 1;
+                    reinterpret_cast<TrackerRecord *>(W->D.li_rec)[chunk_first + pkt] = rec;
                 }
             }
             state = WS_NEED_TRACE;
@@ -859,19 +958,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     // set_packet_collection_output (modes/montecarlo_transport.py:70-90)
                     C->out_nu[i] = p.nu;
                     C->out_e[i] = (p.status == ST_REABSORBED) ? -p.energy : p.energy;
-                    if (TRACK) {
-                        const bool any = trk_any;
-                        const double nan = __builtin_nan("");
-                        C->li_nu[i] = any ? p.nu : nan;
-                        C->li_energy[i] = any ? p.energy : nan;
-                        C->li_after_nu[i] = any ? p.nu : nan;
-                        C->li_after_energy[i] = any ? p.energy : nan;
-                        if (!any) {  // no interaction at all: the fields an interaction would have written
-                            C->li_radius[i] = nan; C->li_before_nu[i] = nan; C->li_before_mu[i] = nan; C->li_before_energy[i] = nan;
-                            C->li_after_mu[i] = nan;
-                            C->li_shell_id[i] = -1; C->li_interaction_type[i] = -1; C->li_line_absorb_id[i] = -1; C->li_line_emit_id[i] = -1;
-                        }
-                        C->li_interactions_count[i] = trk_count;
+                    if (TRACK && !trk_any) {  // no interaction at all: an empty record (the unpacking fills in NaN / -1 / 0)
+                        TrackerRecord rec;
+                        rec.before_nu = rec.before_mu = rec.before_energy = rec.radius = rec.after_mu = 0.0;
+                        rec.shell = rec.type = rec.absorb = rec.emit = -1; rec.count = 0; rec.valid = 0;
+                        reinterpret_cast<TrackerRecord *>(C->li_rec)[i] = rec;
                     }
                 }
                 state = WS_NEED_PACKET;

@@ -98,6 +98,9 @@ struct TardisMcContext {
     // opacity
     int n_lines = 0, n_trans = 0, n_levels = 0;
     DevBuf nu_line, tau_t, n_e, prob_t, cum_t, trans_nu, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec, bucket_first;
+    DevBuf cum16, rec8, quad_info, line_block_c;  // compact walk tables (walk_tables.hpp)
+    unsigned cum16_stride = 0;
+    bool have_walk_tables = false;
     int bucket_shift = 0, bucket_n = 0;
     long long bucket_kmin = 0;
     bool lines_sorted = true;  // line_list_nu strictly usable by the index-based kernels (non-increasing, positive)
@@ -113,7 +116,7 @@ struct TardisMcContext {
     // packets
     long long n_packets = 0;
     DevBuf r0, mu0, nu0, e0, seeds, out_nu, out_e;
-    DevBuf li_f64[9], li_i64[5];
+    DevBuf li_f64[9], li_i64[5], li_rec;  // (li_rec: the wave kernel's 64-byte tracker records, unpacked into the arrays after the propagation)
     bool track = true;
     // v-packet log
     DevBuf vlog_count, vlog_packet, vlog_seq, vlog_nu, vlog_energy, vlog_mu, vlog_r;
@@ -447,6 +450,7 @@ mc::DeviceProblem make_device_problem(TardisMcContext *ctx)
         long long **g[] = {&P.li_shell_id, &P.li_interaction_type, &P.li_line_absorb_id, &P.li_line_emit_id,
                            &P.li_interactions_count};
         for (int k = 0; k < 5; ++k) *g[k] = ctx->li_i64[k].as<long long>();
+        P.li_rec = ctx->li_rec.as<uint4>();
     }
     P.n_shells = ctx->n_shells;
     P.r_inner = ctx->r_inner.as<double>(); P.r_outer = ctx->r_outer.as<double>();
@@ -561,6 +565,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     ctx->seed_chk[0].release(); ctx->seed_chk[1].release(); ctx->vp_scratch[0].release(); ctx->vp_scratch[1].release();
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
+    ctx->li_rec.release();
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -714,6 +719,58 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
             ctx->prob_negative = neg != 0;
         }
     }
+    ctx->have_walk_tables = false;
+    if (macro && E > 1 && !ctx->prob_negative) {
+        // compact tables of the per-lane macro-atom walk (walk_tables.hpp): blocks at 16-byte aligned compact offsets
+        const size_t n_levels = E - 1;
+        std::vector<long long> c0(n_levels + 1);
+        long long tc = 0;
+        for (size_t b = 0; b < n_levels; ++b) {
+            c0[b] = tc;
+            tc += (o->macro_block_edge_index[b + 1] - o->macro_block_edge_index[b] + 7) / 8 * 8;
+        }
+        c0[n_levels] = tc;
+        const long long n_quads = tc / 8;
+        const unsigned long long stride = (unsigned long long)tc + mc::WALK_SLACK;
+        if (tc > 0 && stride * S < (1ull << 32) && tc < (1LL << 30)) {
+            std::vector<int> qi(2 * (size_t)n_quads), lbc(2 * L, 0);
+            std::vector<unsigned> r8(2 * (size_t)tc, 0u);
+            for (size_t b = 0; b < n_levels; ++b) {
+                const long long b0 = o->macro_block_edge_index[b], b1 = o->macro_block_edge_index[b + 1];
+                for (long long q = c0[b] / 8, k = b0; k < b1; ++q, k += 8) { qi[2 * q] = (int)k; qi[2 * q + 1] = (int)(b1 - k); }
+                for (long long k = b0; k < b1; ++k) {
+                    const long long c = c0[b] + (k - b0);
+                    const int64_t tt = o->transition_type[k];
+                    if (tt >= 0) {
+                        const int64_t lvl = o->destination_level_id[k];
+                        r8[2 * c] = (unsigned)c0[lvl];
+                        r8[2 * c + 1] = (unsigned)(o->macro_block_edge_index[lvl + 1] - o->macro_block_edge_index[lvl]);
+                    } else if (tt == -1) {
+                        r8[2 * c] = (unsigned)o->transition_line_id[k];
+                        r8[2 * c + 1] = mc::WALK_EMIT;
+                    } else
+                        r8[2 * c + 1] = mc::WALK_EMIT | mc::WALK_UNSUPPORTED;
+                }
+            }
+            for (size_t i = 0; i < L; ++i) {
+                const int64_t lvl = o->line2macro_level_upper[i];
+                lbc[2 * i] = (int)c0[lvl];
+                lbc[2 * i + 1] = (int)(o->macro_block_edge_index[lvl + 1] - o->macro_block_edge_index[lvl]);
+            }
+            if ((rc = upload(ctx, ctx->quad_info, qi.data(), qi.size()))) return rc;
+            if ((rc = upload(ctx, ctx->rec8, r8.data(), r8.size()))) return rc;
+            if ((rc = upload(ctx, ctx->line_block_c, lbc.data(), lbc.size()))) return rc;
+            HIP_TRY(ctx, ctx->cum16.ensure((size_t)stride * S * sizeof(unsigned short)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->cum16.p, 0xff, (size_t)stride * S * sizeof(unsigned short), ctx->stream));
+            const long long n = n_quads * (long long)S;
+            hipLaunchKernelGGL(mc::walk_cum16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->cum_t.as<double>(),
+                               ctx->quad_info.as<int2>(), n_quads, (long long)T, (int)S, (unsigned)stride, ctx->cum16.as<unsigned short>());
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the host vectors above are the sources of asynchronous copies)
+            ctx->cum16_stride = (unsigned)stride;
+            ctx->have_walk_tables = true;
+        }
+    }
     ctx->lines_sorted = true;
     for (size_t i = 0; i < L; ++i)
         if (!(o->line_list_nu[i] > 0.0) || (i > 0 && !(o->line_list_nu[i] <= o->line_list_nu[i - 1]))) { ctx->lines_sorted = false; break; }
@@ -790,6 +847,7 @@ int tardis_mc_set_packets(TardisMcContext *ctx, const TardisMcPackets *p)
     if (ctx->track) {
         for (auto &b : ctx->li_f64) HIP_TRY(ctx, b.ensure(P * sizeof(double)));
         for (auto &b : ctx->li_i64) HIP_TRY(ctx, b.ensure(P * sizeof(long long)));
+        HIP_TRY(ctx, ctx->li_rec.ensure(P * 64));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_packets = (long long)P;
@@ -861,6 +919,7 @@ static int ensure_packet_buffers(TardisMcContext *ctx, size_t P)
     if (ctx->track) {
         for (auto &b : ctx->li_f64) HIP_TRY(ctx, b.ensure(P * sizeof(double)));
         for (auto &b : ctx->li_i64) HIP_TRY(ctx, b.ensure(P * sizeof(long long)));
+        HIP_TRY(ctx, ctx->li_rec.ensure(P * 64));
     }
     return TARDIS_MC_OK;
 }
@@ -1003,6 +1062,12 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     }
     const TardisMcConfig &c = ctx->cfg;
     const bool vpk = c.number_of_vpackets > 0;
+    if (ctx->track) {  // (tracking may have been switched on after the packets were set)
+        const size_t P = (size_t)std::max<long long>(ctx->n_packets, 1);
+        for (auto &b : ctx->li_f64) HIP_TRY(ctx, b.ensure(P * sizeof(double)));
+        for (auto &b : ctx->li_i64) HIP_TRY(ctx, b.ensure(P * sizeof(long long)));
+        HIP_TRY(ctx, ctx->li_rec.ensure(P * 64));
+    }
     // v-packet log buffers
     if (c.enable_vpacket_tracking && vpk) {
         // (sized for the current call: the engine is cached per process, a later, larger run must not inherit a smaller log)
@@ -1115,6 +1180,14 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         P.delta_nu = F.delta_nu; P.vhist = F.vhist;
         P.bucket_first = ctx->bucket_first.as<int>(); P.bucket_shift = ctx->bucket_shift; P.bucket_n = ctx->bucket_n;
         P.bucket_kmin = ctx->bucket_kmin;
+        // macroatom mode of the wave kernel: per-lane walk on the compact tables (walk_tables.hpp); debug flag 8192 keeps the
+        // cooperative group scan of the fp64 running sums, 128 the per-lane search in them (both for cross-checks)
+        const bool compact_walk = wave_kernel && c.line_interaction_type == 2 && ctx->have_walk_tables && !(ctx->debug_flags & (128 | 8192));
+        if (compact_walk) {
+            P.cum16 = ctx->cum16.as<unsigned short>(); P.rec8 = ctx->rec8.as<uint2>(); P.quad_info = ctx->quad_info.as<int2>();
+            P.cum16_stride = ctx->cum16_stride;
+            P.line_block = ctx->line_block_c.as<int2>();
+        }
         // group size: 8 lanes per packet pays off when the sweeps between events are short (sparse line lists)
         const int G = ctx->group_size == 8 ? 8 : (ctx->group_size == 16 ? 16 : ((ctx->n_lines <= 100000 && !vpk) ? 8 : 16));
         const int block = 256;
@@ -1296,6 +1369,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         if (two_streams) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
+        if (wave_kernel && ctx->track && ctx->n_packets > 0) {  // the wave kernel's tracker records -> the boundary's arrays
+            hipLaunchKernelGGL(mc::tracker_unpack_kernel, dim3((unsigned)((ctx->n_packets + 255) / 256)), dim3(256), 0, ctx->stream, F,
+                               ctx->n_packets);
+            HIP_TRY(ctx, hipGetLastError());
         }
     }
     {   // events per packet of this call, for the log sizing of the next one (asynchronous, pinned host memory)

@@ -1,0 +1,47 @@
+"""Timing experiments on the BASELINE configs[2] table shape (GPU box): one engine, a list of option sets.
+    python tools/exp_cfg3.py [packets] [name=value,name=value ...]...
+Each argument after the packet count is one experiment: comma-separated engine options (variant, debug_flags, group_size,
+ls_min_active, ls_max_steps, waves_per_simd, blocks_per_cu, track_last_interaction ...)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tardis_amd import synthetic  # noqa: E402
+from tardis_amd.engine import Engine  # noqa: E402
+
+P = int(float(sys.argv[1])) if len(sys.argv) > 1 else 5_000_000
+exps = sys.argv[2:] or ["variant=-1"]
+shape = dict(n_shells=20, n_lines=500_000, line_interaction_type="macroatom")
+if os.environ.get("EXP_SHAPE") == "config2":
+    shape = dict(n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+prob = synthetic.make_problem(seed=1, n_packets=1, **shape)
+eng = Engine(0)
+eng.set_geometry(prob.geometry, prob.time_explosion)
+eng.set_opacity(prob.opacity_state)
+eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+defaults = {"variant": -1, "debug_flags": 0, "group_size": 0, "lane_sweep_min_active": 8, "lane_sweep_max_steps": 1 << 30, "waves_per_simd": 4,
+            "track_last_interaction": 1}
+ref = None
+for e in exps:
+    opts = dict(defaults)
+    for kv in e.split(","):
+        if kv:
+            k, v = kv.split("=")
+            opts[k] = int(v)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    eng.create_blackbody_packets(P, float(prob.geometry.r_inner[0]), 1.0e4)
+    best = 1e30
+    for _ in range(2):
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        best = min(best, eng.last_propagate_ms())
+    kt = eng.last_kernel_times()
+    c = eng.last_counters()
+    sig = (c["line_visits"], c["events"], c["macro_transitions"], c["rng_draws"])
+    if ref is None:
+        ref = sig
+    print(f"{e:60s} {best:9.2f} ms  {P / best / 1e3:7.2f} Mpkt/s  propagate {kt['propagate_ms']:8.2f} ms x{kt['launches']}  "
+          f"est {kt['estimator_ms']:7.2f} ms  counters {'same' if sig == ref else 'DIFFER ' + str(sig)}  c7={c['reserved']}", flush=True)
+eng.close()

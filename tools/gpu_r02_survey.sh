@@ -5,8 +5,8 @@
 set -u
 TAG=${1:-r02_cfg3}; PKTS=${2:-5000000}; shift 2 || true
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-python tools/micro_r02.py > "$OUT/micro.txt" 2>&1
-BENCH="python $ROOT/bench.py --config 3 --packets $PKTS --steps 2 --warmup 1 --cpu-sample 0 $*"
+if [ "${MICRO:-0}" = "1" ]; then python tools/micro_r02.py > "$OUT/micro.txt" 2>&1; fi
+BENCH="python $ROOT/bench.py --config 3 --packets $PKTS --steps 2 --warmup 1 --cpu-sample 0 --boundary-packets 0 $*"
 cd /tmp
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
 timeout -k 5 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace_bench.log" 2>&1
