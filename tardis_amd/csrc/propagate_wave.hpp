@@ -31,7 +31,7 @@ namespace mc {
 constexpr int WV_STATE_STRIDE = 624;  // words between the MT19937 states of two packets
 constexpr int WV_RING = 8, WV_RING_VPK = 16;  // look-ahead doubles per packet (power of two; a refill adds 4, so it needs r_cnt <= 4).  16 with 8-double
                             // refills was measured: fewer refill rounds, but the extra 4 KiB of LDS costs the 12th wave of the CU
-enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3 };
+enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3, WS_WALK = 4 };  // WS_WALK: a macro-atom walk carried over to the next pass
 constexpr int RES_PENDING = -1;
 constexpr int WV_RESERVE = 32;  // packets a wave reserves per atomic on the chunk's packet counter
 
@@ -74,8 +74,34 @@ struct WaveHot {
     double t_exp, tc, rcp_tc;
     const int2 *line_block;           // lane sweep: macro-atom block of a line (null unless line_interaction_type != 0), requested as soon as a line stops the trace
     int ls_min_active, ls_max_steps;  // lane sweep: leave the sweep phase once this few lanes are still sweeping / after this many steps
+    int walk_min_active;              // compact macro-atom walk: carry the walks over once this few lanes are still walking (-1: never)
 };
 struct LaunchRec;
+// Suspended state of a lane / of a wave: a propagate call is a sequence of launches ("epochs") of the same grid over ONE
+// packet supply.  A wave whose region of the line-visit log is full stores its lanes here and exits; the estimator passes
+// consume the log while the next epoch -- which writes the other log buffer -- resumes every wave where it stopped.
+// The lanes of a wave therefore never run dry between epochs: the drain of the longest-lived packets (0.26 s per launch on
+// the macroatom shape, one live lane per wave) is paid once per call instead of once per log-bounded chunk.
+struct __attribute__((aligned(16))) LaneSave {
+    double r, mu, nu, energy, dop;
+    double s_tau, s_tau_event, s_kp, s_xb;  // lane sweep in progress
+    double d_cont0, d_boundary;             // sh.d_cont0 / sh.d_boundary (parameters of the running sweep or distance found)
+    double ring[WV_RING_VPK];               // look-ahead doubles of the packet's MT19937 stream
+    int shell, next_line, status, state, pkt, pflags, r_gpos, r_head, r_cnt;
+    int trk_count, trk_boundary, flags;     // flags: 1 trk_any, 2 s_active, 4 s_fast
+    int s_line;
+    unsigned s_row;
+    int res_info, res_line, pre_blk_x, pre_blk_y;
+    unsigned rng_a, rng_b;
+    int vseq;
+    unsigned pred_bits;
+    // a carried-over macro-atom walk (state WS_WALK) and the interaction it belongs to: sh.chi | sh.rcp_chi | sh.nu | sh.rcp_nu | sh.comov_nu
+    double walk_inv_new, walk_block, trk_nu, trk_mu, trk_energy;
+};
+struct WaveSave {
+    long long res_next, res_end;
+    int exhausted, done;
+};
 struct WaveCold {
     GroupArgs P;
     // A copy of the full problem description, NOT read through P.cold: loads through a pointer that was itself loaded from
@@ -87,6 +113,11 @@ struct WaveCold {
     long long chunk_first, chunk_count;
     const LaunchRec *launch;  // [chunk_count] prepared packets (launch_prep_kernel)
     VpResult *vp_scratch;  // [waves][64 * VP_ROUND]
+    // epochs (see LaneSave): where the lanes / waves of this grid are suspended; resume = this launch continues them
+    LaneSave *save;      // [waves * 64]
+    WaveSave *wsave;     // [waves]
+    int resume;
+    unsigned *suspended;  // number of waves this launch suspended (0: the call is complete)
 };
 
 // One worker slot of a group: the trace it is sweeping (group-uniform values) and this lane's line of the current chunk.
@@ -539,7 +570,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     // doubles of a packet; the regenerated words go to the packet's state buffer, from which later blocks read them.
     auto refill = [&](unsigned long long need, uint32_t *seeded_states) {
         if (!((need >> lane) & 1ull)) return;
-        uint32_t *st = seeded_states + (size_t)pkt * WV_STATE_STRIDE;
+        uint32_t *st = seeded_states + ((size_t)blockIdx.x * 64 + (size_t)lane) * WV_STATE_STRIDE;  // (one state buffer per lane of the grid)
         const int k0 = r_gpos & 0x3ff;
         uint32_t wa[9], wc[8];
         if (!(r_gpos >> 16)) {  // first pass over the state
@@ -586,6 +617,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         r_gpos = (k0 + 8 == MT_N) ? 0x10000 : r_gpos + 8;  // bit 16: the state has been regenerated once
     };
 
+    if (W->resume) {  // continue where the previous epoch suspended this wave
+        const WaveSave ws = W->wsave[blockIdx.x];
+        res_next = ws.res_next; res_end = ws.res_end; exhausted = ws.exhausted != 0;
+        if (ws.done) state = WS_DONE;
+        else {
+            const LaneSave &v = W->save[(size_t)blockIdx.x * 64 + lane];
+            p.r = v.r; p.mu = v.mu; p.nu = v.nu; p.energy = v.energy; dop = v.dop;
+            s_tau = v.s_tau; s_tau_event = v.s_tau_event; s_kp = v.s_kp; s_xb = v.s_xb;
+            sh.d_cont0[lane] = v.d_cont0; sh.d_boundary[lane] = v.d_boundary;
+#pragma unroll
+            for (int q = 0; q < RING; ++q) ring[q * 64 + lane] = v.ring[q];
+            p.shell = v.shell; p.next_line_id = v.next_line; p.status = v.status; state = v.state; pkt = v.pkt; pflags = v.pflags;
+            r_gpos = v.r_gpos; r_head = v.r_head; r_cnt = v.r_cnt;
+            trk_count = v.trk_count; trk_boundary = v.trk_boundary;
+            trk_any = (v.flags & 1) != 0; s_active = (v.flags & 2) != 0; s_fast = (v.flags & 4) != 0;
+            s_line = v.s_line; s_row = v.s_row;
+            sh.res_info[lane] = v.res_info; sh.res_line[lane] = v.res_line; pre_blk = make_int2(v.pre_blk_x, v.pre_blk_y);
+            sh.rng_a[lane] = v.rng_a; sh.rng_b[lane] = v.rng_b;
+            vseq = v.vseq; pred_bits = v.pred_bits;
+            sh.chi[lane] = v.walk_inv_new; sh.rcp_chi[lane] = v.walk_block;
+            sh.nu[lane] = v.trk_nu; sh.rcp_nu[lane] = v.trk_mu; sh.comov_nu[lane] = v.trk_energy;
+        }
+    }
+    bool suspended = false;
     unsigned dbg_passes = 0;
 #ifdef TMC_SECTION_TIMERS  // profiling builds only: wall time of the sections of a pass, section (debug_flags >> 8) & 7 -> counters[7]
     unsigned long long sec_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -603,6 +658,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         uint32_t *const seeded_states = W->seeded_states;
         const long long chunk_first = W->chunk_first, chunk_count = W->chunk_count;
         double *const jb = P.jblue_t, *const ed = P.edot_t;
+        if (W->save && log.region_capacity > 0 && log_used + 64 > log.region_capacity) {
+            // this wave's region of the line-visit log is full: suspend the lanes as they are (every lane is at the top of a
+            // pass: a swept trace waiting for its event, a lane sweep in progress, or done) and leave the rest to the next epoch
+            LaneSave v;
+            v.r = p.r; v.mu = p.mu; v.nu = p.nu; v.energy = p.energy; v.dop = dop;
+            v.s_tau = s_tau; v.s_tau_event = s_tau_event; v.s_kp = s_kp; v.s_xb = s_xb;
+            v.d_cont0 = sh.d_cont0[lane]; v.d_boundary = sh.d_boundary[lane];
+#pragma unroll
+            for (int q = 0; q < WV_RING_VPK; ++q) v.ring[q] = q < RING ? ring[q * 64 + lane] : 0.0;
+            v.shell = p.shell; v.next_line = p.next_line_id; v.status = p.status; v.state = state; v.pkt = pkt; v.pflags = pflags;
+            v.r_gpos = r_gpos; v.r_head = r_head; v.r_cnt = r_cnt;
+            v.trk_count = trk_count; v.trk_boundary = trk_boundary;
+            v.flags = (trk_any ? 1 : 0) | (s_active ? 2 : 0) | (s_fast ? 4 : 0);
+            v.s_line = s_line; v.s_row = s_row;
+            v.res_info = sh.res_info[lane]; v.res_line = sh.res_line[lane]; v.pre_blk_x = pre_blk.x; v.pre_blk_y = pre_blk.y;
+            v.rng_a = sh.rng_a[lane]; v.rng_b = sh.rng_b[lane];
+            v.vseq = vseq; v.pred_bits = pred_bits;
+            v.walk_inv_new = sh.chi[lane]; v.walk_block = sh.rcp_chi[lane];
+            v.trk_nu = sh.nu[lane]; v.trk_mu = sh.rcp_nu[lane]; v.trk_energy = sh.comov_nu[lane];
+            W->save[(size_t)blockIdx.x * 64 + lane] = v;
+            suspended = true;
+            break;
+        }
         // every live packet gets the draws of one pass: new direction, first macro-atom jump, next tau_event
         const bool ready = state == WS_SWEEP && !(LS && s_active);  // the prepared trace has been swept
         refill(__ballot((ready || state == WS_NEED_TRACE) && r_cnt < 3), seeded_states);
@@ -610,6 +688,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         double inv_new = 1.0, distance = 0.0;
         bool in_macro = false, interacted = false;
         bool want_volley = false;  // this lane's packet launches a volley of v-packets in this pass
+        // a macro-atom walk that the previous pass left unfinished (the wave does not wait for its longest chains): the line
+        // interaction it belongs to is complete up to the jump, what the rest of the pass needs was parked in LDS
+        const bool resumed = state == WS_WALK;
+        if (resumed) {
+            in_macro = true; interacted = true; type = IT_LINE;
+            inv_new = sh.chi[lane];
+            const int2 blk = reinterpret_cast<const int2 *>(sh.rcp_chi)[lane];
+            mb0 = blk.x; mb1 = blk.y;
+        }
         // ---- log the line visits of the finished traces (update_line_estimators, deferred: estimator_log.hpp)
         {
             int n_visit = 0, start = 0;
@@ -709,8 +796,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             // jump one 16..64-byte read of the block's 16-bit running sums (all of a block of <= 32 transitions; longer blocks
             // are first narrowed by a binary search over their 8-entry quads) and one 8-byte read of what the selected
             // transition leads to.  64 jumps of a wave are in flight at once; here mb0 / mb1 = compact start / rows of the block.
-            for (;;) {
-                if (!__ballot(in_macro)) break;
+            for (int round = 0;; ++round) {
+                const unsigned long long walking = __ballot(in_macro);
+                if (!walking) break;
+                // the wave does not wait for its longest chains (a geometric tail: each jump ends a walk with the probability
+                // of an emission): once few lanes are still walking and others wait (their interaction is complete, or their
+                // sweep goes on), those few carry their walk over to the next pass
+                // (not with v-packets: the pooled volleys reuse the LDS in which a carried walk parks its interaction)
+                if (!VPK && round > 0 && __popcll(walking) <= H.walk_min_active && __ballot(!in_macro && state != WS_DONE)) break;
                 refill(__ballot(in_macro && r_cnt < 1), seeded_states);
                 double event = 0.0;
                 unsigned x = 0;
@@ -772,6 +865,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         } else { mb0 = (int)rec.x; mb1 = (int)rec.y; }
                     }
                 }
+            }
+            if (in_macro) {  // carried over
+                state = WS_WALK;
+                sh.chi[lane] = inv_new;
+                reinterpret_cast<int2 *>(sh.rcp_chi)[lane] = make_int2(mb0, mb1);
             }
         } else if (P.line_interaction_type == 2 && !(P.debug_flags & 128)) {  // (flag 128: the per-lane search below, for tests)
             // macroatom mode (long chains of jumps, and a wave waits for its longest chain: one coalesced round trip per jump): the wave's G-lane groups scan the blocks, G
@@ -871,6 +969,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 }
             }
         }
+        const bool carried = state == WS_WALK && in_macro;  // (set above, compact walk only)
+        if (carried) in_macro = false;
         // downbranch (one jump over a short block)
         bool have_emit_nu = false;
         double emit_nu = 0.0;
@@ -922,7 +1022,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         }
         TMC_SEC(2)
         // ---- finish the interaction, hand finished packets over
-        if (ready) {
+        if ((ready || resumed) && !carried) {
             if (interacted && !err) {
                 int emit_id = -1;
                 const int absorb_id = (type == IT_LINE) ? p.next_line_id : -1;  // (the line that absorbed the packet)
@@ -1362,6 +1462,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     }
 
     if (lane == 0 && W->log.region_capacity > 0) W->log.region_count[blockIdx.x] = min(log_used, W->log.region_capacity);
+    if (lane == 0 && W->wsave) {
+        WaveSave ws;
+        ws.res_next = res_next; ws.res_end = res_end; ws.exhausted = exhausted ? 1 : 0; ws.done = suspended ? 0 : 1;
+        W->wsave[blockIdx.x] = ws;
+        if (suspended) atomicAdd(W->suspended, 1u);
+    }
     const DeviceProblem *C = &W->D;
     for (int s = lane; s < H.n_shells; s += 64) {
         if (lds_J[s] != 0.0) atomic_add_f64(&C->J[s], lds_J[s]);

@@ -129,6 +129,7 @@ struct TardisMcContext {
     // launch geometry
     int variant = -1;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel, group sweeps; 3: wave-owner kernel, lane sweeps; -1: automatic
     bool prob_negative = false;  // a negative transition probability: the running sums are not monotone, no jump search
+    int walk_min_active = 8;  // compact macro-atom walk: carry the longest chains over to the next pass once this few lanes still walk (-1: never)
     int ls_min_active = 8, ls_max_steps = 1 << 30;  // lane sweeps: when to leave the sweep phase (propagate_wave.hpp)
     int blocks_per_cu = 16;
     int debug_flags = 0;
@@ -148,6 +149,14 @@ struct TardisMcContext {
     unsigned long long *events_host = nullptr;  // pinned: {events counter of the last propagate, its packet count}
     hipEvent_t ev_events = nullptr;
     std::vector<mc::WaveCold> wave_cold_host;
+    // wave kernel: a propagate call is a sequence of epochs over one packet supply (LaneSave, propagate_wave.hpp)
+    DevBuf lane_save, wave_save, suspended_dev;
+    unsigned *suspended_host = nullptr;  // pinned
+    hipEvent_t ev_post[4] = {nullptr, nullptr, nullptr, nullptr};  // start / end of the estimator passes on log buffer set 0 / 1
+    bool wave_epoch_mode = false, post_pending[2] = {false, false}, prop_pending = false;
+    double sum_seed_ms = 0.0, sum_prop_ms = 0.0, sum_post_ms = 0.0;
+    int launches = 0;
+    int log_sets = 2;
     int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
     // RCCL
     void *comm = nullptr;
@@ -566,6 +575,10 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
     ctx->li_rec.release();
+    ctx->cum16.release(); ctx->rec8.release(); ctx->quad_info.release(); ctx->line_block_c.release();
+    ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
+    if (ctx->suspended_host) (void)hipHostFree(ctx->suspended_host);
+    for (hipEvent_t e : ctx->ev_post) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -593,9 +606,11 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
     else if (n == "lane_sweep_min_active") ctx->ls_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "lane_sweep_max_steps") ctx->ls_max_steps = (int)std::max<long long>(1, value);
+    else if (n == "walk_min_active") ctx->walk_min_active = (int)std::max<long long>(-1, std::min<long long>(value, 63));
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
     else if (n == "pipeline_chunks") ctx->pipeline_chunks = std::max(1, (int)value);
     else if (n == "log_capacity") ctx->log_capacity = std::max<long long>(0, value);
+    else if (n == "log_sets") ctx->log_sets = value == 1 ? 1 : 2;  // 1: the estimator passes of an epoch run before the next epoch, not beside it
     else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
     else return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return TARDIS_MC_OK;
@@ -1092,11 +1107,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // the cooperative kernel relies on a sorted line list (bucket index, monotone stopping predicate); anything else --
     // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
     // automatic choice: the wave-owner kernel (its pooled v-packet volleys take up to 32 v-packets per volley: one bit of
-    // the roulette predictor each; beyond that the lane-per-packet kernel)
-    // automatic choice: the wave-owner kernel; lane sweeps where their bounds hold (partial relativity) and where they were
-    // measured to win: short traces between events (downbranch / scatter line lists, no volleys).  The macroatom shapes
-    // (5e5 lines, ~36 lines per trace, chains of ~20 jumps per interaction) run 19 % faster with group sweeps.
-    const bool prefer_lane_sweeps = !c.enable_full_relativity && !vpk && c.line_interaction_type != 2;
+    // the roulette predictor each; beyond that the lane-per-packet kernel); lane sweeps where their bounds hold (partial
+    // relativity) and no volleys run.  On the macroatom shape (5e5 lines, ~36 lines per trace) the lane sweeps overtook the
+    // group sweeps once the walk ran per lane on the compact tables and a call became epochs over one packet supply
+    // (19.3 vs 13.4 Mpkt/s at 2e7 packets): the group sweeps' 280 instructions per 16-line step had become the bound.
+    const bool prefer_lane_sweeps = !c.enable_full_relativity && !vpk;
     int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : (prefer_lane_sweeps ? 3 : 2));
     if (ctx->prob_negative && (variant == 2 || variant == 3)) variant = 1;  // (the wave kernel searches the monotone running sums)
     const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2 || variant == 3) && (!vpk || c.number_of_vpackets <= 32);
@@ -1117,46 +1132,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             HIP_TRY(ctx, hipGetLastError());
         }
     } else {
-        // variant 1: cooperative kernel; MT19937 states are seeded per chunk by a lane-per-packet kernel
-        long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
-        // wave-owner kernel (lane-per-packet event code and v-packet volleys, groups as sweep and macro-atom workers)
+        // variant 1: group kernel, chunked (MT19937 states are seeded per chunk by a lane-per-packet kernel);
+        // variants 2 / 3: wave-owner kernel, one packet supply for the whole call, launched in epochs (see LaneSave)
         const bool wave_kernel = variant == 2 || variant == 3;
-        if (wave_kernel && ctx->pipeline_chunks > 1 && ctx->n_packets >= (2LL << 20)) {
-            // pipeline: ~pipeline_chunks chunks of at least 1 Mi packets, alternating between two streams
-            const long long want = (ctx->n_packets + ctx->pipeline_chunks - 1) / ctx->pipeline_chunks;
-            chunk = std::min(chunk, std::max<long long>(1LL << 20, (want + 65535) / 65536 * 65536));
-        }
-        // the line-visit log of a chunk must fit log_capacity: 1.5x the traces per packet measured in the last iteration (128
-        // per packet before anything was measured), one region per wave; a region that overflows falls back to atomics
-        if (ctx->events_host && ctx->ev_events && hipEventQuery(ctx->ev_events) == hipSuccess && ctx->events_host[1] > 0)
-            ctx->traces_per_packet = (double)ctx->events_host[0] / (double)ctx->events_host[1];
-        // (the budget only ever grows, and only when the measured need comes within 20 % of it: resizing a 30 GB log costs more
-        // than an iteration)
-        if (1.2 * ctx->traces_per_packet > ctx->log_budget_per_packet) ctx->log_budget_per_packet = 1.5 * ctx->traces_per_packet;
-        const double log_per_packet = ctx->log_budget_per_packet;
-        if (wave_kernel && ctx->log_capacity > 0)
-            chunk = std::max<long long>(1 << 16, std::min<long long>(chunk, (long long)((double)ctx->log_capacity / log_per_packet)));
-        // Several chunks (asked for, or forced by the log / state buffers): alternate them between two streams, so that the
-        // drain of one chunk's last, longest-lived packets overlaps the start of the next chunk (+9 % on the macroatom
-        // shape with two log-bounded chunks).  Needs a second set of chunk buffers: only if they fit comfortably.
-        bool two_streams = wave_kernel && chunk < ctx->n_packets && ctx->pipeline_chunks > 1;
-        if (wave_kernel && chunk < ctx->n_packets && ctx->pipeline_chunks == 1 && !ctx->stream2) {
-            size_t free_b = 0, total_b = 0;
-            const double extra = (double)chunk * ((double)mc::WV_STATE_STRIDE * sizeof(uint32_t) + sizeof(mc::LaunchRec) +
-                                                  log_per_packet * (sizeof(mc::LineVisitRecord) + 2.0 * sizeof(unsigned)));
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 2.0 * extra < 0.6 * (double)free_b) two_streams = true;
-        } else if (wave_kernel && chunk < ctx->n_packets && ctx->stream2)
-            two_streams = true;  // (the buffers of an earlier call are still there)
-        if (two_streams && !ctx->stream2) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        }
-        HIP_TRY(ctx, ctx->seeded_states.ensure((size_t)chunk * mc::WV_STATE_STRIDE * sizeof(uint32_t)));
-        if (two_streams) {
-            HIP_TRY(ctx, ctx->seeded_states2.ensure((size_t)chunk * mc::WV_STATE_STRIDE * sizeof(uint32_t)));
-            HIP_TRY(ctx, ctx->next_packet2.ensure(sizeof(unsigned long long)));
-        }
         ctx->problem_host = make_device_problem(ctx);
         const mc::DeviceProblem &F = ctx->problem_host;
         HIP_TRY(ctx, ctx->problem_dev.ensure(sizeof(mc::DeviceProblem)));
@@ -1170,6 +1148,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         P.tc = F.t_exp * mc::C_LIGHT; P.rcp_tc = 1.0 / P.tc;
         if ((long long)ctx->n_shells * ctx->n_lines >= (1LL << 28) || (long long)ctx->n_shells * ctx->n_trans >= (1LL << 28))
             return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells * n_lines exceeds the 32-bit table offsets of the cooperative kernel");
+        if (wave_kernel && ctx->n_packets >= (1LL << 31))
+            return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "more than 2^31 packets per propagate call");
         P.r_inner = F.r_inner; P.r_outer = F.r_outer; P.nu_line = F.nu_line; P.tau_t = F.tau_t; P.n_e = F.n_e; P.prob_t = F.prob_t;
         P.line_block = ctx->line_block.as<int2>(); P.trans_rec = ctx->trans_rec.as<int4>();
         P.cum_t = ctx->cum_t.as<double>(); P.trans_nu = ctx->trans_nu.as<double>();
@@ -1188,192 +1168,244 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             P.cum16_stride = ctx->cum16_stride;
             P.line_block = ctx->line_block_c.as<int2>();
         }
-        // group size: 8 lanes per packet pays off when the sweeps between events are short (sparse line lists)
-        const int G = ctx->group_size == 8 ? 8 : (ctx->group_size == 16 ? 16 : ((ctx->n_lines <= 100000 && !vpk) ? 8 : 16));
-        const int block = 256;
-        const size_t lds = G == 8 ? mc::group_kernel_lds_bytes<8, 256>(ctx->n_shells) : mc::group_kernel_lds_bytes<16, 256>(ctx->n_shells);
-        if (lds > 160 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
-        const int blocks_per_cu = std::max(1, std::min(std::min(ctx->blocks_per_cu, 8), (int)((160 * 1024) / lds)));
-        using KernelFn = void (*)(mc::GroupArgs, uint32_t *, long long, long long);
-        KernelFn k;
         const bool full = c.enable_full_relativity != 0, trk = ctx->track;
-        const bool lane_sweep = variant == 3 && !full;  // (the bounds of the lane sweep are those of partial relativity)
-        const size_t wave_lds = lane_sweep ? (vpk ? mc::wave_kernel_lds_bytes<false, true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false, true>(ctx->n_shells))
-                              : vpk ? (full ? mc::wave_kernel_lds_bytes<true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, true>(ctx->n_shells))
-                                    : (full ? mc::wave_kernel_lds_bytes<true, false>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false>(ctx->n_shells));
-        if (wave_kernel && wave_lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
-        const int wave_waves_per_cu = std::max(1, std::min(ctx->waves_per_simd > 0 ? 4 * ctx->waves_per_simd : 16, (int)((160 * 1024) / wave_lds)));
-#define TMC_PICK2(G_, V_) (full ? (trk ? mc::propagate_group_kernel<true, true, G_, 256, 4, V_> : mc::propagate_group_kernel<true, false, G_, 256, 4, V_>) \
-                                : (trk ? mc::propagate_group_kernel<false, true, G_, 256, 4, V_> : mc::propagate_group_kernel<false, false, G_, 256, 4, V_>))
-        if (G == 16) k = vpk ? TMC_PICK2(16, true) : TMC_PICK2(16, false);
-        else k = vpk ? TMC_PICK2(8, true) : TMC_PICK2(8, false);
-#undef TMC_PICK2
-        using WaveKernelFn = void (*)(mc::WaveHot, const mc::WaveCold *);
-        WaveKernelFn kw = nullptr;
+        while ((int)ctx->ev_chunk.size() < 8) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->ev_chunk.push_back(e);
+        }
+        ctx->chunks_timed = 0;
+        ctx->sum_seed_ms = ctx->sum_prop_ms = ctx->sum_post_ms = 0.0;
+        ctx->launches = 0;
+        if (wave_kernel) {
+            const bool lane_sweep = variant == 3 && !full;  // (the bounds of the lane sweep are those of partial relativity)
+            const size_t wave_lds = lane_sweep ? (vpk ? mc::wave_kernel_lds_bytes<false, true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false, true>(ctx->n_shells))
+                                  : vpk ? (full ? mc::wave_kernel_lds_bytes<true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, true>(ctx->n_shells))
+                                        : (full ? mc::wave_kernel_lds_bytes<true, false>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false>(ctx->n_shells));
+            if (wave_lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
+            const int wave_waves_per_cu = std::max(1, std::min(ctx->waves_per_simd > 0 ? 4 * ctx->waves_per_simd : 16, (int)((160 * 1024) / wave_lds)));
+            using WaveKernelFn = void (*)(mc::WaveHot, const mc::WaveCold *);
+            WaveKernelFn kw = nullptr;
 #define TMC_PICKW2(G_, V_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_, V_> : mc::propagate_wave_kernel<true, false, G_, V_>) \
                                  : (trk ? mc::propagate_wave_kernel<false, true, G_, V_> : mc::propagate_wave_kernel<false, false, G_, V_>))
 #define TMC_PICKW(G_) (vpk ? TMC_PICKW2(G_, true) : TMC_PICKW2(G_, false))
 #define TMC_PICKLS(G_, V_) (trk ? mc::propagate_wave_kernel<false, true, G_, V_, true> : mc::propagate_wave_kernel<false, false, G_, V_, true>)
-        // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel)
-        const int GW = ctx->group_size ? ctx->group_size : (ctx->n_lines <= 100000 ? 8 : 16);
-        if (wave_kernel && lane_sweep) kw = (GW == 16) ? (vpk ? TMC_PICKLS(16, true) : TMC_PICKLS(16, false)) : (vpk ? TMC_PICKLS(8, true) : TMC_PICKLS(8, false));
-        else if (wave_kernel) kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
+            // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel)
+            const int GW = ctx->group_size ? ctx->group_size : (ctx->n_lines <= 100000 ? 8 : 16);
+            if (lane_sweep) kw = (GW == 16) ? (vpk ? TMC_PICKLS(16, true) : TMC_PICKLS(16, false)) : (vpk ? TMC_PICKLS(8, true) : TMC_PICKLS(8, false));
+            else kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
 #undef TMC_PICKLS
 #undef TMC_PICKW2
 #undef TMC_PICKW
-        // estimator log of the wave kernel (estimator_log.hpp)
-        mc::EstimatorLog elog{};
-        int n_bins = 0;
-        unsigned long long log_cap = 0;
-        if (wave_kernel) {
-            const int tiles = (ctx->n_lines + mc::EST_TILE - 1) / mc::EST_TILE;
-            n_bins = ctx->n_shells * std::max(tiles, 1);
+            const long long n = ctx->n_packets;
+            const int waves = (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, (long long)cus * wave_waves_per_cu));
+            // ---- the line-visit log (estimator_log.hpp): two buffer sets, one region per wave; an epoch ends when the regions
+            // are full.  Sized for the whole call when that fits log_capacity (1.2x the traces per packet measured in the last
+            // call, 128 per packet before anything was measured), else log_capacity.
+            if (ctx->events_host && ctx->ev_events && hipEventQuery(ctx->ev_events) == hipSuccess && ctx->events_host[1] > 0)
+                ctx->traces_per_packet = (double)ctx->events_host[0] / (double)ctx->events_host[1];
+            if (1.1 * ctx->traces_per_packet > ctx->log_budget_per_packet) ctx->log_budget_per_packet = 1.3 * ctx->traces_per_packet;
+            const int tiles = std::max((ctx->n_lines + mc::EST_TILE - 1) / mc::EST_TILE, 1);
+            const int n_bins = ctx->n_shells * tiles;
             unsigned long long cap = std::min<unsigned long long>((unsigned long long)ctx->log_capacity,
-                                                                  (unsigned long long)((double)chunk * log_per_packet) + 65536ull);
-            if (n_bins > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernels add their terms directly
+                                                                  (unsigned long long)((double)n * ctx->log_budget_per_packet) + 64ull * (unsigned long long)waves + 65536ull);
+            if (n_bins > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernel adds its terms directly
             cap = std::min<unsigned long long>(cap, 0xfffffff0ull);
-            for (int b = 0; b < (two_streams ? 2 : 1); ++b) {
-                HIP_TRY(ctx, ctx->log_records[b].ensure(std::max<size_t>(cap, 1) * sizeof(mc::LineVisitRecord)));
-                HIP_TRY(ctx, ctx->log_keys[b].ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
-                HIP_TRY(ctx, ctx->log_sorted[b].ensure(std::max<size_t>(cap, 1) * sizeof(unsigned)));
+            unsigned region_capacity = (unsigned)std::min<unsigned long long>(cap / (unsigned long long)waves, 0x7fffffffull);
+            if (region_capacity > 0 && region_capacity < 256) region_capacity = 256;  // (an epoch must make progress: >= 64 records per pass)
+            // (waves take packets dynamically, so any wave may fill its region before the others: every launch can suspend)
+            const bool may_suspend = region_capacity > 0;
+            // a second buffer set (the estimator passes of an epoch overlap the next epoch) only when the call may need several epochs
+            const int n_sets = ctx->log_sets == 1 ? 1 : ((region_capacity > 0 && (unsigned long long)region_capacity * waves < (unsigned long long)((double)n * ctx->log_budget_per_packet)) ? 2 : 1);
+            const size_t set_records = (size_t)std::max<unsigned long long>((unsigned long long)region_capacity * waves, 1);
+            for (int b = 0; b < n_sets; ++b) {
+                HIP_TRY(ctx, ctx->log_records[b].ensure(set_records * sizeof(mc::LineVisitRecord)));
+                HIP_TRY(ctx, ctx->log_keys[b].ensure(set_records * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->log_sorted[b].ensure(set_records * sizeof(unsigned)));
                 HIP_TRY(ctx, ctx->log_bins[b].ensure((size_t)(4 * (n_bins + 2)) * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->log_cursor[b].ensure((size_t)waves * sizeof(unsigned)));
             }
-            elog.tiles_per_shell = std::max(tiles, 1);
-            log_cap = cap;
-        }
-        // (the log is split into one region per wave of a launch: set_log_regions fills in the rest)
-        auto set_log_regions = [&](mc::EstimatorLog &lg, int b, int n_regions, hipStream_t st) -> hipError_t {
-            lg.records = ctx->log_records[b].as<mc::LineVisitRecord>();
-            lg.keys = ctx->log_keys[b].as<unsigned>();
-            lg.n_regions = n_regions;
-            lg.region_capacity = (unsigned)std::min<unsigned long long>(log_cap / (unsigned long long)std::max(n_regions, 1), 0x7fffffffull);
-            hipError_t e = ctx->log_cursor[b].ensure((size_t)std::max(n_regions, 1) * sizeof(unsigned));
-            if (e != hipSuccess) return e;
-            lg.region_count = ctx->log_cursor[b].as<unsigned>();
-            return hipMemsetAsync(lg.region_count, 0, (size_t)std::max(n_regions, 1) * sizeof(unsigned), st);
-        };
-        // binning + accumulation of one chunk's line-visit log (estimator_log.hpp)
-        auto estimator_passes = [&](const mc::EstimatorLog &lg, int b, hipStream_t st) -> hipError_t {
-            if (lg.region_capacity == 0) return hipSuccess;
-            unsigned *bin_count = ctx->log_bins[b].as<unsigned>(), *bin_start = bin_count + (n_bins + 1),
-                     *bin_fill = bin_start + (n_bins + 1), *slice_start = bin_fill + (n_bins + 1);
-            unsigned *sorted = ctx->log_sorted[b].as<unsigned>();
-            hipError_t e = hipMemsetAsync(bin_count, 0, (size_t)(n_bins + 1) * sizeof(unsigned), st);
-            if (e != hipSuccess) return e;
-            const size_t hist_lds = (size_t)n_bins * sizeof(unsigned);
-            if (hist_lds > 64 * 1024) {  // more than the default dynamic-LDS limit: BASELINE config 5 has 100 shells x 245 tiles
-                e = hipFuncSetAttribute((const void *)mc::bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
-                if (e != hipSuccess) return e;
-                e = hipFuncSetAttribute((const void *)mc::bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
-                if (e != hipSuccess) return e;
+            if (n_sets == 2 && !ctx->stream2) {
+                HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
             }
-            const int bin_blocks = cus * 8;
-            hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.region_count, lg.n_regions,
-                               lg.region_capacity, n_bins, bin_count);
-            hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, st, bin_count, n_bins, bin_start, bin_fill, slice_start);
-            hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, st, lg.keys, lg.region_count, lg.n_regions,
-                               lg.region_capacity, n_bins, bin_fill, sorted);
-            const unsigned acc_blocks = (unsigned)(cus * 3);
-            if (full)
-                hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
-                                   slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
-            else
-                hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, st, lg.records, sorted, bin_start,
-                                   slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
-            return hipGetLastError();
-        };
-        if (wave_kernel) {
-            const size_t n_chunks = (size_t)((ctx->n_packets + chunk - 1) / chunk) + 1;
-            HIP_TRY(ctx, ctx->wave_cold_dev.ensure(n_chunks * sizeof(mc::WaveCold)));
-            ctx->wave_cold_host.reserve(n_chunks);
-        }
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-        if (two_streams) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        }
-        ctx->chunks_timed = 0;
-        for (long long first = 0; first < ctx->n_packets; first += chunk) {
-            const long long count = std::min(chunk, ctx->n_packets - first);
-            const int ci = ctx->chunks_timed;
-            const int b = two_streams ? (ci & 1) : 0;
-            hipStream_t st = b ? ctx->stream2 : ctx->stream;
-            uint32_t *seeded = (b ? ctx->seeded_states2 : ctx->seeded_states).as<uint32_t>();
-            unsigned long long *next_packet = (b ? ctx->next_packet2 : ctx->next_packet).as<unsigned long long>();
-            while ((int)ctx->ev_chunk.size() < 4 * (ci + 1)) {
-                hipEvent_t e;
-                HIP_TRY(ctx, hipEventCreate(&e));
-                ctx->ev_chunk.push_back(e);
-            }
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci], st));
-            if (wave_kernel) {
+            for (int k = 0; k < 4; ++k)
+                if (!ctx->ev_post[k]) HIP_TRY(ctx, hipEventCreate(&ctx->ev_post[k]));
+            // ---- per-lane MT19937 state buffers, launch records, suspended lanes
+            HIP_TRY(ctx, ctx->seeded_states.ensure((size_t)waves * 64 * mc::WV_STATE_STRIDE * sizeof(uint32_t)));
+            HIP_TRY(ctx, ctx->seed_chk[0].ensure((size_t)std::max<long long>(n, 1) * sizeof(mc::LaunchRec)));
+            HIP_TRY(ctx, ctx->lane_save.ensure((size_t)waves * 64 * sizeof(mc::LaneSave)));
+            HIP_TRY(ctx, ctx->wave_save.ensure((size_t)waves * sizeof(mc::WaveSave)));
+            HIP_TRY(ctx, ctx->suspended_dev.ensure(sizeof(unsigned)));
+            if (!ctx->suspended_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->suspended_host, sizeof(unsigned), hipHostMallocDefault));
+            if (vpk) HIP_TRY(ctx, ctx->vp_scratch[0].ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(mc::VpResult)));
+            HIP_TRY(ctx, ctx->wave_cold_dev.ensure(2 * sizeof(mc::WaveCold)));
+            ctx->wave_cold_host.resize(2);
+            hipStream_t st = ctx->stream;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[0], st));
+            if (n > 0) {
                 // lazy seeding: only word 397 of every start state is precomputed; the refills continue the init_genrand chains
-                HIP_TRY(ctx, ctx->seed_chk[b].ensure((size_t)count * sizeof(mc::LaunchRec)));
-                {
-                    mc::LaunchPrepArgs la{};
-                    la.r0 = F.r0; la.mu0 = F.mu0; la.nu0 = F.nu0; la.e0 = F.e0; la.nu_line = P.nu_line;
-                    la.seeds = ctx->seeds.as<uint32_t>();
-                    la.bucket_first = P.bucket_first; la.bucket_shift = P.bucket_shift; la.bucket_n = P.bucket_n; la.n_lines = P.n_lines;
-                    la.bucket_kmin = P.bucket_kmin; la.t_exp = P.t_exp;
-                    la.out = ctx->seed_chk[b].as<mc::LaunchRec>(); la.first = first; la.count = count;
-                    if (full) hipLaunchKernelGGL(mc::launch_prep_kernel<true>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, la);
-                    else hipLaunchKernelGGL(mc::launch_prep_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, la);
-                }
+                mc::LaunchPrepArgs la{};
+                la.r0 = F.r0; la.mu0 = F.mu0; la.nu0 = F.nu0; la.e0 = F.e0; la.nu_line = P.nu_line;
+                la.seeds = ctx->seeds.as<uint32_t>();
+                la.bucket_first = P.bucket_first; la.bucket_shift = P.bucket_shift; la.bucket_n = P.bucket_n; la.n_lines = P.n_lines;
+                la.bucket_kmin = P.bucket_kmin; la.t_exp = P.t_exp;
+                la.out = ctx->seed_chk[0].as<mc::LaunchRec>(); la.first = 0; la.count = n;
+                if (full) hipLaunchKernelGGL(mc::launch_prep_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, la);
+                else hipLaunchKernelGGL(mc::launch_prep_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, la);
                 HIP_TRY(ctx, hipGetLastError());
-            } else {
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[1], st));
+            mc::WaveHot hot{};
+            hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
+            hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
+            hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
+            hot.ls_min_active = ctx->ls_min_active; hot.ls_max_steps = ctx->ls_max_steps;
+            hot.walk_min_active = ctx->walk_min_active;
+            hot.line_block = P.line_interaction_type != 0 ? P.line_block : nullptr;
+            // binning + accumulation of one epoch's line-visit log (estimator_log.hpp)
+            auto estimator_passes = [&](const mc::EstimatorLog &lg, int b, hipStream_t es) -> hipError_t {
+                if (lg.region_capacity == 0) return hipSuccess;
+                unsigned *bin_count = ctx->log_bins[b].as<unsigned>(), *bin_start = bin_count + (n_bins + 1),
+                         *bin_fill = bin_start + (n_bins + 1), *slice_start = bin_fill + (n_bins + 1);
+                unsigned *sorted = ctx->log_sorted[b].as<unsigned>();
+                hipError_t e = hipMemsetAsync(bin_count, 0, (size_t)(n_bins + 1) * sizeof(unsigned), es);
+                if (e != hipSuccess) return e;
+                const size_t hist_lds = (size_t)n_bins * sizeof(unsigned);
+                if (hist_lds > 64 * 1024) {  // more than the default dynamic-LDS limit: BASELINE config 5 has 100 shells x 245 tiles
+                    e = hipFuncSetAttribute((const void *)mc::bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
+                    if (e != hipSuccess) return e;
+                    e = hipFuncSetAttribute((const void *)mc::bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
+                    if (e != hipSuccess) return e;
+                }
+                const int bin_blocks = cus * 8;
+                hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, es, lg.keys, lg.region_count, lg.n_regions,
+                                   lg.region_capacity, n_bins, bin_count);
+                hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, es, bin_count, n_bins, bin_start, bin_fill, slice_start);
+                hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, es, lg.keys, lg.region_count, lg.n_regions,
+                                   lg.region_capacity, n_bins, bin_fill, sorted);
+                const unsigned acc_blocks = (unsigned)(cus * 3);
+                if (full)
+                    hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, es, lg.records, sorted, bin_start,
+                                       slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                else
+                    hipLaunchKernelGGL(mc::accumulate_kernel<false>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, es, lg.records, sorted, bin_start,
+                                       slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                return hipGetLastError();
+            };
+            ctx->post_pending[0] = ctx->post_pending[1] = false;
+            ctx->prop_pending = false;
+            const int max_epochs = 1 << 20;
+            for (int epoch = 0; n > 0 && epoch < max_epochs; ++epoch) {
+                const int b = n_sets == 2 ? (epoch & 1) : 0;
+                hipStream_t es = n_sets == 2 ? ctx->stream2 : st;  // the estimator passes of an epoch run beside the next epoch
+                if (ctx->post_pending[b]) {  // this buffer set was used two epochs ago: its estimator passes must be over
+                    float ms = 0.f;
+                    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_post[2 * b + 1]));
+                    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_post[2 * b], ctx->ev_post[2 * b + 1]));
+                    ctx->sum_post_ms += ms;
+                    ctx->post_pending[b] = false;
+                }
+                mc::EstimatorLog lg{};
+                lg.tiles_per_shell = tiles;
+                lg.records = ctx->log_records[b].as<mc::LineVisitRecord>();
+                lg.keys = ctx->log_keys[b].as<unsigned>();
+                lg.n_regions = waves;
+                lg.region_capacity = region_capacity;
+                lg.region_count = ctx->log_cursor[b].as<unsigned>();
+                HIP_TRY(ctx, hipMemsetAsync(lg.region_count, 0, (size_t)waves * sizeof(unsigned), st));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->suspended_dev.p, 0, sizeof(unsigned), st));
+                mc::WaveCold &wc = ctx->wave_cold_host[epoch & 1];
+                wc.P = P; wc.D = F; wc.log = lg; wc.seeded_states = ctx->seeded_states.as<uint32_t>();
+                wc.chunk_first = 0; wc.chunk_count = n;
+                wc.launch = ctx->seed_chk[0].as<mc::LaunchRec>();
+                wc.vp_scratch = ctx->vp_scratch[0].as<mc::VpResult>();
+                wc.save = may_suspend ? ctx->lane_save.as<mc::LaneSave>() : nullptr;
+                wc.wsave = may_suspend ? ctx->wave_save.as<mc::WaveSave>() : nullptr;
+                wc.resume = epoch > 0 ? 1 : 0;
+                wc.suspended = ctx->suspended_dev.as<unsigned>();
+                mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + (epoch & 1);
+                HIP_TRY(ctx, store_value(st, wc_dev, wc));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[2], st));
+                hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
+                HIP_TRY(ctx, hipGetLastError());
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3], st));
+                if (may_suspend) {  // (read back before the estimator passes are queued: the host learns early whether another epoch follows)
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host, ctx->suspended_dev.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4], st));
+                }
+                if (es != st) HIP_TRY(ctx, hipStreamWaitEvent(es, ctx->ev_chunk[3], 0));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_post[2 * b], es));
+                HIP_TRY(ctx, estimator_passes(lg, b, es));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_post[2 * b + 1], es));
+                ctx->post_pending[b] = true;
+                ctx->launches += 1;
+                ctx->prop_pending = true;
+                if (!may_suspend) break;  // (no log: the kernel adds its terms directly and never suspends; the call stays asynchronous)
+                // is anything suspended?  (the only host synchronisation of a call: once per epoch)
+                HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chunk[4]));
+                float ms = 0.f;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_chunk[2], ctx->ev_chunk[3]));
+                ctx->sum_prop_ms += ms;
+                ctx->prop_pending = false;
+                if (*ctx->suspended_host == 0) break;
+            }
+            if (n_sets == 2 && (ctx->post_pending[0] || ctx->post_pending[1])) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            }
+            ctx->wave_epoch_mode = true;
+            if (ctx->track && n > 0) {  // the wave kernel's tracker records -> the boundary's arrays
+                hipLaunchKernelGGL(mc::tracker_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, F, n);
+                HIP_TRY(ctx, hipGetLastError());
+            }
+        } else {
+            ctx->wave_epoch_mode = false;
+            long long chunk = std::min<long long>(std::max<long long>(ctx->n_packets, 1), ctx->chunk_packets);
+            HIP_TRY(ctx, ctx->seeded_states.ensure((size_t)chunk * mc::WV_STATE_STRIDE * sizeof(uint32_t)));
+            // group size: 8 lanes per packet pays off when the sweeps between events are short (sparse line lists)
+            const int G = ctx->group_size == 8 ? 8 : (ctx->group_size == 16 ? 16 : ((ctx->n_lines <= 100000 && !vpk) ? 8 : 16));
+            const int block = 256;
+            const size_t lds = G == 8 ? mc::group_kernel_lds_bytes<8, 256>(ctx->n_shells) : mc::group_kernel_lds_bytes<16, 256>(ctx->n_shells);
+            if (lds > 160 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
+            const int blocks_per_cu = std::max(1, std::min(std::min(ctx->blocks_per_cu, 8), (int)((160 * 1024) / lds)));
+            using KernelFn = void (*)(mc::GroupArgs, uint32_t *, long long, long long);
+            KernelFn k;
+#define TMC_PICK2(G_, V_) (full ? (trk ? mc::propagate_group_kernel<true, true, G_, 256, 4, V_> : mc::propagate_group_kernel<true, false, G_, 256, 4, V_>) \
+                                : (trk ? mc::propagate_group_kernel<false, true, G_, 256, 4, V_> : mc::propagate_group_kernel<false, false, G_, 256, 4, V_>))
+            if (G == 16) k = vpk ? TMC_PICK2(16, true) : TMC_PICK2(16, false);
+            else k = vpk ? TMC_PICK2(8, true) : TMC_PICK2(8, false);
+#undef TMC_PICK2
+            hipStream_t st = ctx->stream;
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
+            uint32_t *seeded = ctx->seeded_states.as<uint32_t>();
+            for (long long first = 0; first < ctx->n_packets; first += chunk) {
+                const long long count = std::min(chunk, ctx->n_packets - first);
+                const int ci = ctx->chunks_timed;
+                while ((int)ctx->ev_chunk.size() < 4 * (ci + 1)) {
+                    hipEvent_t e;
+                    HIP_TRY(ctx, hipEventCreate(&e));
+                    ctx->ev_chunk.push_back(e);
+                }
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci], st));
                 hipLaunchKernelGGL(mc::seed_states_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
                                    ctx->seeds.as<uint32_t>(), seeded, first, count, mc::MT_N);
                 HIP_TRY(ctx, hipGetLastError());
-            }
-            HIP_TRY(ctx, hipMemsetAsync(next_packet, 0, sizeof(unsigned long long), st));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 1], st));
-            const int groups_per_block = block / G;
-            long long want_blocks = (count + groups_per_block - 1) / groups_per_block;
-            int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)cus * blocks_per_cu));
-            if (wave_kernel) {
-                const long long want_waves = (count + 63) / 64;
-                const int waves = (int)std::max<long long>(1, std::min<long long>(want_waves, (long long)cus * wave_waves_per_cu));
-                mc::EstimatorLog lg = elog;
-                HIP_TRY(ctx, set_log_regions(lg, b, waves, st));
-                // cold arguments of this launch: one device slot per chunk (the host copies stay alive in ctx->wave_cold_host)
-                if ((int)ctx->wave_cold_host.size() <= ci) ctx->wave_cold_host.resize(ci + 1);
-                mc::WaveCold &wc = ctx->wave_cold_host[ci];
-                wc.P = P; wc.P.next_packet = next_packet; wc.D = F; wc.log = lg; wc.seeded_states = seeded;
-                wc.chunk_first = first; wc.chunk_count = count;
-                wc.launch = ctx->seed_chk[b].as<mc::LaunchRec>();
-                if (vpk) HIP_TRY(ctx, ctx->vp_scratch[b].ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(mc::VpResult)));
-                wc.vp_scratch = ctx->vp_scratch[b].as<mc::VpResult>();
-                mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + ci;
-                HIP_TRY(ctx, store_value(st, wc_dev, wc));
-                mc::WaveHot hot{};
-                hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
-                hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
-                hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
-                hot.ls_min_active = ctx->ls_min_active; hot.ls_max_steps = ctx->ls_max_steps;
-                hot.line_block = P.line_interaction_type != 0 ? P.line_block : nullptr;
-                hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
-                HIP_TRY(ctx, hipGetLastError());
-                HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));
-                HIP_TRY(ctx, estimator_passes(lg, b, st));
-            } else {
+                HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), st));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 1], st));
+                const int groups_per_block = block / G;
+                long long want_blocks = (count + groups_per_block - 1) / groups_per_block;
+                int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)cus * blocks_per_cu));
                 // (the group kernel updates the line estimators with atomics: logging its traces was measured and is a loss
                 // there -- the record bookkeeping costs its redundant-lane event loop more than the deferred atomics do)
                 hipLaunchKernelGGL(k, dim3(blocks), dim3(block), lds, st, P, seeded, first, count);
                 HIP_TRY(ctx, hipGetLastError());
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 2], st));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 3], st));
+                ctx->chunks_timed = ci + 1;
             }
-            HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4 * ci + 3], st));
-            ctx->chunks_timed = ci + 1;
-        }
-        if (two_streams) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        }
-        if (wave_kernel && ctx->track && ctx->n_packets > 0) {  // the wave kernel's tracker records -> the boundary's arrays
-            hipLaunchKernelGGL(mc::tracker_unpack_kernel, dim3((unsigned)((ctx->n_packets + 255) / 256)), dim3(256), 0, ctx->stream, F,
-                               ctx->n_packets);
-            HIP_TRY(ctx, hipGetLastError());
         }
     }
     {   // events per packet of this call, for the log sizing of the next one (asynchronous, pinned host memory)
@@ -1419,6 +1451,28 @@ int tardis_mc_last_kernel_times(TardisMcContext *ctx, double *out_seed_ms, doubl
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
     double seed = 0.0, prop = 0.0;
+    if (ctx->wave_epoch_mode) {  // wave kernel: launch preparation once, then one propagation launch + estimator passes per epoch
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_chunk[0], ctx->ev_chunk[1]));
+        ctx->sum_seed_ms = ms;
+        if (ctx->prop_pending) {
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_chunk[2], ctx->ev_chunk[3]));
+            ctx->sum_prop_ms += ms;
+            ctx->prop_pending = false;
+        }
+        for (int b = 0; b < 2; ++b)
+            if (ctx->post_pending[b]) {
+                HIP_TRY(ctx, hipEventSynchronize(ctx->ev_post[2 * b + 1]));
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_post[2 * b], ctx->ev_post[2 * b + 1]));
+                ctx->sum_post_ms += ms;
+                ctx->post_pending[b] = false;
+            }
+        ctx->last_post_ms = ctx->sum_post_ms;
+        if (out_seed_ms) *out_seed_ms = ctx->sum_seed_ms;
+        if (out_propagate_ms) *out_propagate_ms = ctx->sum_prop_ms;
+        if (out_launches) *out_launches = std::max(ctx->launches, 1);
+        return TARDIS_MC_OK;
+    }
     if (ctx->chunks_timed == 0) {  // lane-per-packet variant: one launch, no seeding kernel
         float ms = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));

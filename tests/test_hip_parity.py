@@ -267,24 +267,26 @@ def test_rccl_allreduce_single_rank(engine, oracle):
 
 def test_baseline_config2_full_size(engine, oracle):
     """BASELINE.json configs[1] at full size (1e7 packets, 20 shells, 3e4 lines, downbranch) through size-independent
-    properties: every packet terminates, the work counters add up, chunked launches (4 chunks) reproduce the single
-    launch bit for bit per packet and to 1e-11 in the estimators, and a 1e5-packet sample equals the oracle."""
+    properties: every packet terminates, the work counters add up, a call split into several epochs by a small line-visit
+    log (the lanes are suspended and resumed) reproduces the single launch bit for bit per packet and to 1e-11 in the
+    estimators, and a 1e5-packet sample equals the oracle."""
     from tardis_amd import spectrum
     prob = synthetic.make_problem(seed=1, **synthetic.BASELINE_CONFIGS[2])
     pc = prob.packet_collection
     P = pc.number_of_packets
     assert P == 10_000_000
-    engine.set_option("chunk_packets", 16 << 20)
     hist, vt, eb, el, _, c1 = run_hip(engine, prob, track=False)
+    assert engine.last_kernel_times()["launches"] == 1
     nus, ens = pc.output_nus.copy(), pc.output_energies.copy()
     assert c1["packets"] == P and c1["events"] >= P and c1["line_visits"] >= c1["events"]
     assert not np.any(ens == -99.0) and np.all(np.isfinite(nus)) and np.all(nus > 0)
     emitted = ens >= 0
     assert 0.2 < emitted.mean() < 0.6
-    # chunked launches
-    engine.set_option("chunk_packets", 3_000_000)
+    # several epochs
+    engine.set_option("log_capacity", 60_000_000)
     _, _, eb2, el2, _, c2 = run_hip(engine, prob, track=False)
-    engine.set_option("chunk_packets", 16 << 20)
+    assert engine.last_kernel_times()["launches"] >= 3
+    engine.set_option("log_capacity", 1_500_000_000)
     assert np.array_equal(pc.output_nus, nus) and np.array_equal(pc.output_energies, ens)
     assert c1 == c2
     assert_allclose(eb2.mean_intensity_total, eb.mean_intensity_total, rtol=EST_RTOL)
@@ -379,25 +381,32 @@ def test_kernel_variants_and_options_agree_with_the_oracle(oracle, options, mode
 
 
 @pytest.mark.gpu
-def test_chunked_two_stream_pipeline_matches(oracle):
-    """pipeline_chunks > 1 splits a propagate call into chunks on two streams (only for >= 2 Mi packets)."""
+@pytest.mark.parametrize("variant", [2, 3])
+def test_epochs_match_a_single_launch(oracle, variant):
+    """A small line-visit log splits a propagate call into epochs (the waves suspend their lanes when their log region is
+    full and resume in the next launch, whose estimator passes overlap it on a second stream): same per-packet results,
+    trackers and counters as the single launch."""
     from tardis_amd.engine import Engine
     prob = synthetic.make_problem(seed=19, n_packets=(2 << 20) + 777, n_shells=6, n_lines=2_000, line_interaction_type="downbranch")
     outs = []
-    for chunks in (1, 2):
+    for cap in (1_500_000_000, 2_500_000):
         eng = Engine(0)
-        eng.set_option("pipeline_chunks", chunks)
-        eng.set_option("track_last_interaction", 0)
+        eng.set_option("variant", variant)
+        eng.set_option("log_capacity", cap)
         eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
         eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
         eng.reset_estimators(); eng.propagate(); eng.synchronize()
-        outs.append(eng.get_results(track_last_interaction=False))
-        assert (eng.last_kernel_times()["launches"] == 1) == (chunks == 1)
+        outs.append(eng.get_results(track_last_interaction=True))
+        launches = eng.last_kernel_times()["launches"]
+        assert launches == 1 if cap > 1_000_000_000 else launches >= 3
         eng.close()
     a, b = outs
     assert np.array_equal(a.output_nus, b.output_nus) and np.array_equal(a.output_energies, b.output_energies)
+    for f in st.LastInteractionTrackers.I64_FIELDS + st.LastInteractionTrackers.F64_FIELDS:
+        assert np.array_equal(getattr(a.trackers, f), getattr(b.trackers, f), equal_nan=True), f
     assert_allclose(a.j_blue_estimator, b.j_blue_estimator, rtol=EST_RTOL)
-    assert a.counters["events"] == b.counters["events"]
+    assert_allclose(a.j_estimator, b.j_estimator, rtol=EST_RTOL)
+    assert a.counters == b.counters
 
 
 @pytest.mark.gpu
@@ -459,20 +468,20 @@ def test_negative_transition_probability_keeps_the_serial_walk(oracle, mode):
 
 
 @pytest.mark.gpu
-def test_log_bounded_chunks_alternate_between_two_streams(oracle):
-    """A call whose line-visit log does not fit log_capacity is split into chunks, which alternate between two streams (the
-    drain of one chunk overlaps the start of the next): same results as the oracle, several launches."""
+def test_log_bounded_epochs_match_the_oracle(oracle):
+    """A call whose line-visit log does not fit log_capacity runs as several epochs (suspended and resumed lanes, two log
+    buffer sets): same results as the oracle, several launches; repeated, the call reuses its buffers."""
     from tardis_amd.engine import Engine
     prob = synthetic.make_problem(seed=29, n_packets=300_001, n_shells=6, n_lines=2_000, line_interaction_type="downbranch")
     ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
     eng = Engine(0)
-    eng.set_option("log_capacity", 1 << 23)      # 65536 packets per chunk at the initial budget of 128 traces per packet
+    eng.set_option("log_capacity", 1 << 21)      # 4096 waves x 512 records per epoch
     eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
     eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
     for _ in range(2):
         eng.reset_estimators(); eng.propagate(); eng.synchronize()
         got = eng.get_results(track_last_interaction=True)
-        assert eng.last_kernel_times()["launches"] >= 4
+        assert eng.last_kernel_times()["launches"] >= 2
         assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
         assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
         assert_allclose(got.edotlu_estimator, ref.edotlu_estimator, rtol=EST_RTOL)
