@@ -573,6 +573,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         uint32_t *st = seeded_states + ((size_t)blockIdx.x * 64 + (size_t)lane) * WV_STATE_STRIDE;  // (one state buffer per lane of the grid)
         const int k0 = r_gpos & 0x3ff;
         uint32_t wa[9], wc[8];
+        // (the state words a block needs are contiguous -- mt[k0 .. k0+8] and mt[k0+397 .. k0+404] mod 624 -- except for the one
+        // block whose second window straddles the end of the state: four 16-byte loads instead of seventeen 4-byte ones)
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        typedef v4u v4u_a4 __attribute__((aligned(4)));
+        int cb = k0 + 397;  // first word of the second window
+        if (cb >= MT_N) cb -= MT_N;
+        const bool c_contig = cb + 8 <= MT_N;
+        auto load_c = [&]() {  // wc[0..7] = regenerated words mt[(k0 + 397 + i) mod 624]
+            if (c_contig) {
+                const v4u lo = *reinterpret_cast<const v4u_a4 *>(st + cb), hi = *reinterpret_cast<const v4u_a4 *>(st + cb + 4);
+                wc[0] = lo.x; wc[1] = lo.y; wc[2] = lo.z; wc[3] = lo.w; wc[4] = hi.x; wc[5] = hi.y; wc[6] = hi.z; wc[7] = hi.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wc[i] = st[(cb + i >= MT_N) ? cb + i - MT_N : cb + i];
+            }
+        };
         if (!(r_gpos >> 16)) {  // first pass over the state
             uint32_t w = sh.rng_a[lane];  // mt[k0]
 #pragma unroll
@@ -583,22 +599,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             sh.rng_a[lane] = w;  // mt[k0 + 8]
             if (k0 + 8 == MT_N) wa[8] = st[0];  // word 623 pairs with the NEW word 0
             uint32_t wb = sh.rng_b[lane];  // mt[k0 + 397]
+            uint32_t wi[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                wc[i] = wb;
+                wi[i] = wb;
                 wb = 1812433253u * (wb ^ (wb >> 30)) + (uint32_t)(k0 + 397 + i + 1);
             }
             sh.rng_b[lane] = wb;  // mt[k0 + 405]
             if (k0 + 397 + 7 >= MT_N) {  // (part of) the second window has wrapped: those are regenerated words
+                load_c();
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    if (k0 + 397 + i >= MT_N) wc[i] = st[k0 + 397 + i - MT_N];
+                    if (k0 + 397 + i < MT_N) wc[i] = wi[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wc[i] = wi[i];
             }
         } else {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) wa[i] = st[(k0 + i == MT_N) ? 0 : k0 + i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) wc[i] = st[(k0 + 397 + i >= MT_N) ? k0 + 397 + i - MT_N : k0 + 397 + i];
+            const v4u lo = *reinterpret_cast<const v4u *>(st + k0), hi = *reinterpret_cast<const v4u *>(st + k0 + 4);  // 32-byte aligned
+            wa[0] = lo.x; wa[1] = lo.y; wa[2] = lo.z; wa[3] = lo.w; wa[4] = hi.x; wa[5] = hi.y; wa[6] = hi.z; wa[7] = hi.w;
+            wa[8] = st[(k0 + 8 == MT_N) ? 0 : k0 + 8];
+            load_c();
         }
         uint32_t v[8];
 #pragma unroll
@@ -606,7 +627,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             const uint32_t y = (wa[i] & 0x80000000u) | (wa[i + 1] & 0x7fffffffu);
             v[i] = wc[i] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         }
-        typedef unsigned v4u __attribute__((ext_vector_type(4)));
         v4u *dst = reinterpret_cast<v4u *>(st + k0);  // 32-byte aligned: k0 is a multiple of 8
         v4u lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
         dst[0] = lo4; dst[1] = hi4;
@@ -683,7 +703,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         }
         // every live packet gets the draws of one pass: new direction, first macro-atom jump, next tau_event
         const bool ready = state == WS_SWEEP && !(LS && s_active);  // the prepared trace has been swept
-        refill(__ballot((ready || state == WS_NEED_TRACE) && r_cnt < 3), seeded_states);
+        // (up to the capacity of the ring, so that the refills inside the walk and before the prologue -- each a dependent round
+        // trip of its own -- are rarely needed)
+        refill(__ballot((ready || state == WS_NEED_TRACE || state == WS_WALK) && r_cnt <= RING - 4), seeded_states);
         int err = 0, type = 0, emit = -1, mb0 = 0, mb1 = 0;
         double inv_new = 1.0, distance = 0.0;
         bool in_macro = false, interacted = false;
