@@ -227,7 +227,7 @@ def default_cpu_sample(kw: dict) -> int:
     """~10-30 s of CPU work on a 16-thread box: the C oracle runs ~5e3 packets/s/thread on the 5e5-line macroatom shape
     and ~2e5 on the tardis_example shape."""
     heavy = kw["n_lines"] > 100_000 or kw["line_interaction_type"] == "macroatom" or kw.get("n_vpackets", 0) > 0
-    return 200_000 if heavy else 10_000_000
+    return 800_000 if heavy else 10_000_000
 
 
 def cpu_baseline(prob, eng, P: int, radius: float, n_sample: int) -> dict:

@@ -33,6 +33,7 @@ constexpr int EST_MAX_BINS = 36864;  // largest LDS histogram of the binning ker
 __global__ void __launch_bounds__(256) bin_count_kernel(const unsigned *__restrict__ keys, const unsigned *__restrict__ region_count,
                                                         int n_regions, unsigned region_capacity, int n_bins, unsigned *__restrict__ bin_count)
 {
+    __builtin_amdgcn_s_setprio(3);  // these passes run beside the next epoch's propagation: its (older) waves would otherwise win every issue slot
     extern __shared__ unsigned hist[];
     for (int b = threadIdx.x; b < n_bins; b += 256) hist[b] = 0;
     __syncthreads();
@@ -51,6 +52,7 @@ __global__ void __launch_bounds__(256) bin_count_kernel(const unsigned *__restri
 __global__ void __launch_bounds__(256) bin_scan_kernel(const unsigned *__restrict__ bin_count, int n_bins, unsigned *__restrict__ bin_start,
                                                        unsigned *__restrict__ bin_fill, unsigned *__restrict__ slice_start)
 {
+    __builtin_amdgcn_s_setprio(3);  // these passes run beside the next epoch's propagation: its (older) waves would otherwise win every issue slot
     auto slices = [&](int b) { return (bin_count[b] + EST_SLICE - 1) / EST_SLICE; };
     __shared__ unsigned part_r[256], part_s[256];
     const int per = (n_bins + 255) / 256;
@@ -78,6 +80,7 @@ __global__ void __launch_bounds__(256) bin_scatter_kernel(const unsigned *__rest
                                                           int n_regions, unsigned region_capacity, int n_bins,
                                                           unsigned *__restrict__ bin_fill, unsigned *__restrict__ sorted_index)
 {
+    __builtin_amdgcn_s_setprio(3);  // these passes run beside the next epoch's propagation: its (older) waves would otherwise win every issue slot
     extern __shared__ unsigned hist[];
     for (int b = threadIdx.x; b < n_bins; b += 256) hist[b] = 0;
     __syncthreads();
@@ -117,6 +120,7 @@ __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVi
                                                                     int tiles_per_shell, int n_lines, const double *__restrict__ nu_line,
                                                                     double *__restrict__ jblue_t, double *__restrict__ edot_t)
 {
+    __builtin_amdgcn_s_setprio(3);  // these passes run beside the next epoch's propagation: its (older) waves would otherwise win every issue slot
     constexpr int TILE_LDS = EST_TILE + EST_APRON;
     __shared__ double tile_jb[TILE_LDS], tile_ed[TILE_LDS];
     // staged records, array of structures: a lane fetches "its" record with three 16-byte LDS reads

@@ -749,7 +749,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         const unsigned long long stride = (unsigned long long)tc + mc::WALK_SLACK;
         if (tc > 0 && stride * S < (1ull << 32) && tc < (1LL << 30)) {
             std::vector<int> qi(2 * (size_t)n_quads), lbc(2 * L, 0);
-            std::vector<unsigned> r8(2 * (size_t)tc, 0u);
+            std::vector<unsigned> r8(2 * (size_t)tc + 4, 0u);  // (+ slack: a lane reads 16 bytes at an 8-byte record)
             for (size_t b = 0; b < n_levels; ++b) {
                 const long long b0 = o->macro_block_edge_index[b], b1 = o->macro_block_edge_index[b + 1];
                 for (long long q = c0[b] / 8, k = b0; k < b1; ++q, k += 8) { qi[2 * q] = (int)k; qi[2 * q + 1] = (int)(b1 - k); }
@@ -1226,7 +1226,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 HIP_TRY(ctx, ctx->log_cursor[b].ensure((size_t)waves * sizeof(unsigned)));
             }
             if (n_sets == 2 && !ctx->stream2) {
-                HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+                int prio_lo = 0, prio_hi = 0;  // (the estimator passes' stream: highest priority, their workgroups are dispatched first)
+                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+                HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_hi));
                 HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
                 HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
             }

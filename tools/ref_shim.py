@@ -111,42 +111,89 @@ def install():
         ),
     )
 
-    # ---- astropy: only `units as u` name + Quantity-lite for constants
+    # ---- astropy: `units as u` + a Quantity-lite.  Everything on the paths imported here is already cgs, so a Quantity is its
+    # value plus a unit NAME; the only conversion performed is the one the reference performs, Hz -> Angstrom through
+    # u.spectral() (mc_rad_field_solver.py:136).  ndarray * Quantity defers to the Quantity (as astropy does).
+    import numpy as _np
+
     class Q:
-        def __init__(self, v):
+        __array_priority__ = 1.0e4
+        __array_ufunc__ = None
+
+        def __init__(self, v, unit=""):
             self.value = v
+            self.unit = unit
 
-        def to(self, *a, **k):
-            return self
+        def _v(self, o):
+            return o.value if isinstance(o, Q) else o
 
-        @property
-        def cgs(self):
-            return self
+        def to(self, target=None, equivalencies=None, *a, **k):
+            tname = target.unit if isinstance(target, Q) else str(target or "")
+            if self.unit == "Hz" and tname == "AA":  # u.spectral(): lambda = c / nu
+                return Q(CGS["c"] / _np.asarray(self.value) * 1e8, "AA")
+            return Q(self.value, tname or self.unit)
 
-        @property
-        def esu(self):
-            return self
+        cgs = property(lambda self: self)
+        esu = property(lambda self: self)
+        si = property(lambda self: self)
+
+        def copy(self):
+            return Q(_np.array(self.value, copy=True), self.unit)
+
+        def __len__(self):
+            return len(self.value)
+
+        def __getitem__(self, i):
+            return Q(self.value[i], self.unit)
 
         def __mul__(self, o):
-            return Q(self.value * (o.value if isinstance(o, Q) else o))
+            return Q(self.value * self._v(o), self.unit or getattr(o, "unit", ""))
 
         __rmul__ = __mul__
 
         def __truediv__(self, o):
-            return Q(self.value / (o.value if isinstance(o, Q) else o))
+            return Q(self.value / self._v(o), self.unit)
 
         def __rtruediv__(self, o):
-            return Q(o / self.value)
+            return Q(o / self.value, self.unit)
 
         def __pow__(self, p):
-            return Q(self.value**p)
+            return Q(self.value**p, self.unit)
+
+        def __neg__(self):
+            return Q(-self.value, self.unit)
+
+        def __add__(self, o):
+            return Q(self.value + self._v(o), self.unit)
+
+        __radd__ = __add__
+
+        def __sub__(self, o):
+            return Q(self.value - self._v(o), self.unit)
+
+        def __gt__(self, o):
+            return self.value > self._v(o)
+
+        def __lt__(self, o):
+            return self.value < self._v(o)
+
+        def __ge__(self, o):
+            return self.value >= self._v(o)
+
+        def __le__(self, o):
+            return self.value <= self._v(o)
+
+        def __array__(self, dtype=None, copy=None):
+            return _np.asarray(self.value, dtype=dtype)
 
     class _U:
+        Quantity = Q
+
         def __getattr__(self, n):
-            return Q(1.0)
+            return Q(1.0, n)
 
         def spectral(self):
-            return None
+            return "spectral"
 
     _mod("astropy", units=_U())
     sys.modules["astropy.units"] = _U()
@@ -192,4 +239,61 @@ def load():
         TrackerLastInteraction,
     )
 
+    return types.SimpleNamespace(**locals())
+
+
+def _function_from_reference(path, name, namespace):
+    """Compile ONE function of a reference module from the reference's own source (the module as a whole needs pandas /
+    radioactivedecay data / package metadata at import) and return it; nothing is copied into this repository."""
+    import ast
+
+    src = open(path).read()
+    tree = ast.parse(src)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
+    exec(code, namespace)
+    return namespace[name]
+
+
+def load_next_rows():
+    """The reference's radiation-field solver and black-body packet source (the rows next to the hot path)."""
+    install()
+    import numpy as np
+    import numpy as _np
+
+    try:  # (pandas probes numexpr's version at import: let it load before the stand-in exists)
+        import pandas  # noqa: F401
+    except Exception:
+        pass
+    Q = sys.modules["astropy.units"].Quantity
+
+    # ---- numexpr: evaluate() of an expression over the caller's variables, with numpy's functions (numexpr's own log / exp
+    # kernels differ from numpy's by at most an ulp or two: the fixtures made through this stand-in are compared at 1e-13)
+    def _ne_evaluate(expr, local_dict=None, global_dict=None, **kw):
+        f = sys._getframe(1)
+        ns = {"log": _np.log, "exp": _np.exp, "sqrt": _np.sqrt}
+        for d in (f.f_globals, f.f_locals if local_dict is None else local_dict):
+            for k, v in d.items():
+                ns[k] = _np.asarray(v.value) if isinstance(v, Q) else v
+        return eval(expr, {"__builtins__": {}}, ns)
+
+    if "numexpr" not in sys.modules:
+        _mod("numexpr", evaluate=_ne_evaluate)
+
+    if "tardis.util.base" not in sys.modules:
+        # tardis/util/base.py:279-302 intensity_black_body, with the module-level constants it reads (util/base.py:30-40)
+        ns = {"ne": sys.modules["numexpr"], "np": np, "k_B_cgs": CGS["k_B"], "h_cgs": CGS["h"], "c_cgs": CGS["c"]}
+        fn = _function_from_reference(os.path.join(REF, "util", "base.py"), "intensity_black_body", ns)
+        _mod("tardis.util")
+        _mod("tardis.util.base", intensity_black_body=fn)
+        _mod("tardis.io.hdf_writer_mixin", HDFWriterMixin=type("HDFWriterMixin", (), {}))
+        # (the package __init__ pulls every packet source in, the gamma-ray ones with their pandas / data-file imports)
+        m = _mod("tardis.transport.montecarlo.packet_source")
+        m.__path__ = [REF + "/transport/montecarlo/packet_source"]
+    from tardis.transport.montecarlo.estimators.estimators_bulk import EstimatorsBulk
+    from tardis.transport.montecarlo.estimators.estimators_line import EstimatorsLine
+    from tardis.transport.montecarlo.estimators.mc_rad_field_solver import MCRadiationFieldPropertiesSolver
+    from tardis.transport.montecarlo.packet_source.black_body import BlackBodySimpleSource
+
+    Quantity = sys.modules["astropy.units"].Quantity
     return types.SimpleNamespace(**locals())
