@@ -3,9 +3,10 @@
 Follows MCRadiationFieldPropertiesSolver.solve (tardis/transport/montecarlo/estimators/mc_rad_field_solver.py:37-144),
 DilutePlanckianRadiationField.calculate_mean_intensity (tardis/plasma/radiation_field/planck_rad_field.py:58-73) and
 intensity_black_body (tardis/util/base.py:279-302) on plain arrays with the cgs CODATA-2010 constants of
-tardis/constants.py:1.  PARITY UNPINNED: the reference module needs astropy units and scipy/numexpr at import, which
-this image lacks, and the reference holds no known-answer test for it; the restatement is checked against closed
-forms only (tests/test_radfield.py).
+tardis/constants.py:1.  PINNED: tests/golden/radfield_*.npz hold what the reference's own solver returned in the dev container
+(tools/make_golden_next_rows.py imports it unmodified through tools/ref_shim.py); tests/test_next_rows_golden.py holds this
+restatement to them at 1e-13 (the reference evaluates exp through numexpr, the fixtures through numpy), tests/test_radfield.py
+adds closed-form checks.
 """
 import numpy as np
 

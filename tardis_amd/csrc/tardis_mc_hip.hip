@@ -1114,6 +1114,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     const bool prefer_lane_sweeps = !c.enable_full_relativity && !vpk;
     int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : (prefer_lane_sweeps ? 3 : 2));
     if (ctx->prob_negative && (variant == 2 || variant == 3)) variant = 1;  // (the wave kernel searches the monotone running sums)
+    // Russian roulette with survivors (virtual_packet.py:221-232; the reference's SURVIVAL_PROBABILITY is 0 in every run, nothing
+    // sets it): a surviving v-packet may play again in a later shell, so its draw count is unbounded, while the wave kernel's
+    // pooled volleys budget one roulette draw per v-packet -- such problems run on the group kernel
+    if (vpk && c.survival_probability > 0.0 && (variant == 2 || variant == 3)) variant = 1;
     const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2 || variant == 3) && (!vpk || c.number_of_vpackets <= 32);
 
     if (!cooperative) {

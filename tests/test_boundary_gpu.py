@@ -1,0 +1,122 @@
+"""The result-holder half of the drop-in boundary on the GPU: MCTransportSolverHIP.run,
+MonteCarloTransportState's properties (montecarlo_transport_state.py:106-160) and tracker_last_interaction_df
+(tracker_last_interaction_util.py:33-134), with every value derived from the reference-generated golden of the case; the path a
+real run_classic takes (modes/classic/solver.py:223-267): a Python LIST of per-packet tracker objects, and output arrays
+that are not contiguous."""
+import types
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import _golden
+from tardis_amd import state as st, transport
+
+pytestmark = pytest.mark.gpu
+EST_RTOL = 1e-11
+
+
+@pytest.mark.parametrize("name", ["macroatom_nv3_log", "downbranch_nv0", "scatter_nv0"])
+def test_solver_state_properties_and_tracker_dataframe(name):
+    prob, g = _golden.load_case(name)
+    cfg = prob.montecarlo_configuration
+    mode = {0: "scatter", 1: "downbranch", 2: "macroatom"}[int(cfg.LINE_INTERACTION_TYPE)]
+    solver = transport.MCTransportSolverHIP(prob.spectrum_frequency_grid, cfg, line_interaction_type=mode,
+                                            enable_full_relativity=bool(cfg.ENABLE_FULL_RELATIVITY), device_id=0)
+    ts = solver.initialize_transport_state(prob.packet_collection, prob.geometry, prob.opacity_state, prob.time_explosion,
+                                           no_of_virtual_packets=int(cfg.NUMBER_OF_VPACKETS))
+    hist = solver.run(ts)
+    pc = prob.packet_collection
+    t_sim = 1.0 / float(g["in_radiation_field_luminosity"])
+    # --- properties other TARDIS code reads
+    assert_allclose(ts.output_nu, g["output_nus"], rtol=1e-13, atol=0)
+    assert_allclose(ts.output_energy, g["output_energies"], rtol=1e-13, atol=0)
+    assert ts.output_nu is pc.output_nus and ts.output_energy is pc.output_energies  # mutated in place
+    assert_allclose(ts.j_estimator, g["j_estimator"], rtol=EST_RTOL)
+    assert_allclose(ts.nu_bar_estimator, g["nu_bar_estimator"], rtol=EST_RTOL)
+    stride = int(g["line_estimator_stride"])
+    assert_allclose(ts.j_blue_estimator[::stride], g["j_blue_estimator"], rtol=EST_RTOL)
+    assert_allclose(ts.Edotlu_estimator[::stride], g["edotlu_estimator"], rtol=EST_RTOL)
+    assert ts.j_blue_estimator.shape == (len(g["in_line_list_nu"]), len(g["in_r_inner"]))  # the reference's [L, S] layout
+    assert ts.time_of_simulation == t_sim
+    lum = g["output_energies"] / t_sim
+    mask = g["output_energies"] >= 0
+    assert_allclose(ts.packet_luminosity, lum, rtol=1e-13)
+    assert np.array_equal(ts.emitted_packet_mask, mask)
+    assert_allclose(ts.emitted_packet_nu, g["output_nus"][mask], rtol=1e-13)
+    assert_allclose(ts.reabsorbed_packet_nu, g["output_nus"][~mask], rtol=1e-13)
+    assert_allclose(ts.emitted_packet_luminosity, lum[mask], rtol=1e-13)
+    assert_allclose(ts.reabsorbed_packet_luminosity, -lum[~mask], rtol=1e-13)
+    assert np.all(ts.reabsorbed_packet_luminosity >= 0)
+    assert_allclose(hist, g["v_packets_energy_hist"], rtol=EST_RTOL)
+    if "vpacket_nus" in g:
+        assert ts.virt_logging
+        assert_allclose(ts.virt_packet_nus, g["vpacket_nus"], rtol=1e-13)
+        assert_allclose(ts.virt_packet_energies, g["vpacket_energies"], rtol=1e-13)
+        assert_allclose(ts.virt_packet_initial_mus, g["vpacket_initial_mus"], rtol=1e-13)
+        assert_allclose(ts.virt_packet_initial_rs, g["vpacket_initial_rs"], rtol=1e-13)
+    # --- the last-interaction data frame (tracker_last_interaction_util.py:115-132)
+    df = ts.tracker_last_interaction_df
+    assert list(df.columns) == ["event_id", "last_interaction_type", "status", "radius", "shell_id", "before_nu", "before_mu",
+                                "before_energy", "after_nu", "after_mu", "after_energy", "line_absorb_id", "line_emit_id"]
+    assert df.index.name == "packet_id" and len(df) == pc.number_of_packets
+    assert np.array_equal(df["event_id"].to_numpy(), g["trk_interactions_count"])
+    names = {-1: "NO_INTERACTION", 1: "BOUNDARY", 2: "LINE", 4: "ESCATTERING"}
+    assert list(df["last_interaction_type"].astype(str)) == [names[int(v)] for v in g["trk_interaction_type"]]
+    assert set(df["status"].astype(str)) == {"IN_PROCESS"}
+    assert np.array_equal(df["shell_id"].to_numpy(), g["trk_shell_id"])
+    assert np.array_equal(df["line_absorb_id"].to_numpy(), g["trk_interaction_line_absorb_id"])
+    assert np.array_equal(df["line_emit_id"].to_numpy(), g["trk_interaction_line_emit_id"])
+    for col in ("radius", "before_nu", "before_mu", "before_energy", "after_nu", "after_mu", "after_energy"):
+        assert_allclose(df[col].to_numpy(), g["trk_" + col], rtol=1e-13, atol=0, equal_nan=True, err_msg=col)
+
+
+class _Tracker:  # what run_classic passes: one TrackerLastInteraction per packet (tracker_last_interaction.py:8-254)
+    def __init__(self):
+        for f in st.LastInteractionTrackers.F64_FIELDS:
+            setattr(self, f, -1.0)
+        for f in st.LastInteractionTrackers.I64_FIELDS:
+            setattr(self, f, -1)
+
+
+def test_list_of_trackers_and_strided_outputs():
+    prob, g = _golden.load_case("downbranch_nv0")
+    pc = prob.packet_collection
+    n = pc.number_of_packets
+    nus2, ens2 = np.full(2 * n, -99.0), np.full(2 * n, -99.0)
+    like = types.SimpleNamespace(initial_radii=pc.initial_radii, initial_nus=pc.initial_nus, initial_mus=pc.initial_mus,
+                                 initial_energies=pc.initial_energies, packet_seeds=pc.packet_seeds,
+                                 output_nus=nus2[::2], output_energies=ens2[1::2])  # views with a stride of 16 bytes
+    trackers = [_Tracker() for _ in range(n)]
+    cfg = prob.montecarlo_configuration
+    hist, vt, eb, el = transport.montecarlo_transport_with_vpackets(
+        like, prob.geometry, prob.time_explosion, prob.opacity_state, cfg, prob.spectrum_frequency_grid, trackers,
+        int(cfg.NUMBER_OF_VPACKETS), False, None)
+    assert_allclose(nus2[::2], g["output_nus"], rtol=1e-13, atol=0)
+    assert_allclose(ens2[1::2], g["output_energies"], rtol=1e-13, atol=0)
+    assert np.all(nus2[1::2] == -99.0) and np.all(ens2[::2] == -99.0)  # nothing else was touched
+    for f in _golden.TRACKER_I64:
+        assert [getattr(t, f) for t in trackers] == list(g["trk_" + f]), f
+        assert isinstance(getattr(trackers[0], f), int)
+    for f in ("radius", "before_nu", "after_mu", "after_energy"):
+        assert_allclose(np.array([getattr(t, f) for t in trackers]), g["trk_" + f], rtol=1e-13, atol=0, equal_nan=True, err_msg=f)
+    assert_allclose(eb.mean_intensity_total, g["j_estimator"], rtol=EST_RTOL)
+    assert vt.nus.shape == (1,)  # the placeholder collection of get_vpacket_tracker (modes/montecarlo_transport.py:228-235)
+
+
+def test_scatter_mode_with_the_reference_placeholder_tables():
+    """line_interaction_type scatter with the (1, 1) / size-1 macro tables OpacityState.to_numba builds
+    (opacities/opacity_state.py:199-209), through the whole boundary."""
+    prob, g = _golden.load_case("scatter_nv0")
+    op = prob.opacity_state
+    ref_like = types.SimpleNamespace(
+        electron_density=op.electron_density, line_list_nu=op.line_list_nu, tau_sobolev=op.tau_sobolev,
+        transition_probabilities=np.zeros((1, 1)), line2macro_level_upper=np.zeros(1, np.int64),
+        macro_block_edge_index=np.zeros(1, np.int64), transition_type=np.zeros(1, np.int64),
+        destination_level_id=np.zeros(1, np.int64), transition_line_id=np.zeros(1, np.int64))
+    pc = prob.packet_collection
+    cfg = prob.montecarlo_configuration
+    transport.montecarlo_transport_with_vpackets(pc, prob.geometry, prob.time_explosion, ref_like, cfg,
+                                                 prob.spectrum_frequency_grid, None, 0, False, None)
+    assert_allclose(pc.output_nus, g["output_nus"], rtol=1e-13, atol=0)
+    assert_allclose(pc.output_energies, g["output_energies"], rtol=1e-13, atol=0)

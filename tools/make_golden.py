@@ -55,6 +55,12 @@ CASES = {
     "config1_downbranch": (dict(seed=1, n_packets=4000, n_shells=20, n_lines=30000, line_interaction_type="downbranch",
                                 shell_independent_probabilities=True), dict(_line_estimator_stride=16)),
     "scatter_single_shell": (dict(seed=20, n_packets=800, n_shells=1, n_lines=300, line_interaction_type="scatter"), {}),
+    # Russian roulette with survivors (virtual_packet.py:221-232): optically thick lines so that tau > VPACKET_TAU_RUSSIAN occurs
+    "downbranch_nv2_roulette": (dict(seed=22, n_packets=400, n_shells=8, n_lines=1500, line_interaction_type="downbranch",
+                                     n_vpackets=2, log_tau_mean=-0.5), dict(SURVIVAL_PROBABILITY=0.3, ENABLE_VPACKET_TRACKING=True)),
+    # quirk (iii) of SURVEY 8a: disable_line_scattering with non-zero tau_sobolev (real runs zero tau first, opacity_solver.py:46-56)
+    "scatter_disabled_lines_tau": (dict(seed=21, n_packets=300, n_shells=6, n_lines=400, line_interaction_type="scatter",
+                                        disable_line_scattering=True), {}),
 }
 
 

@@ -1,0 +1,65 @@
+"""DEV-CONTAINER-ONLY: golden vectors of the rows next to the hot path from the reference's own code.
+
+Imports -- UNMODIFIED, through tools/ref_shim.py (stand-ins for astropy.units, numexpr, numba) --
+  * tardis/transport/montecarlo/packet_source/black_body.py  BlackBodySimpleSource.create_packets   (base.py:195-253)
+  * tardis/transport/montecarlo/estimators/mc_rad_field_solver.py  MCRadiationFieldPropertiesSolver.solve (:37-144)
+and runs them on small inputs; inputs and outputs are committed as tests/golden/packet_source_*.npz and radfield_*.npz.
+The estimator inputs of the radiation-field cases come from the CPU oracle's run of a small synthetic problem (the tests
+re-create that problem from its generator arguments and run the HIP engine on it).
+    python tools/make_golden_next_rows.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+import ref_shim  # noqa: E402
+
+ref = ref_shim.load_next_rows()
+Q = ref.Quantity
+from oracle import oracle  # noqa: E402
+from tardis_amd import synthetic  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+# ---- packet source
+for name, n, radius, temperature, base_seed, seed_offset in (
+        ("packet_source_one", 1, 1.2e15, 9974.0, 23111963, 0),
+        ("packet_source_1000", 1000, 1.2e15, 9974.0, 23111963, 3),
+        ("packet_source_4097", 4097, 1.235520e15, 1.0e4, 23111963, 1),
+        ("packet_source_seed", 513, 2.0e15, 6000.0, 4242, 7)):
+    src = ref.BlackBodySimpleSource(Q(radius, "cm"), Q(temperature, "K"), base_seed=base_seed)
+    pc = src.create_packets(n, seed_offset=seed_offset)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), n=n, radius=radius, temperature=temperature, base_seed=base_seed,
+                        seed_offset=seed_offset, initial_radii=pc.initial_radii, initial_nus=pc.initial_nus,
+                        initial_mus=pc.initial_mus, initial_energies=pc.initial_energies, packet_seeds=pc.packet_seeds,
+                        radiation_field_luminosity=pc.radiation_field_luminosity)
+    print(name, n, pc.initial_nus[:2], pc.packet_seeds[:2])
+
+# ---- radiation field
+for name, args, window, w_eps in (
+        ("radfield_downbranch", dict(seed=9, n_packets=6000, n_shells=6, n_lines=500, line_interaction_type="downbranch"), False, 1e-10),
+        ("radfield_window", dict(seed=9, n_packets=6000, n_shells=6, n_lines=500, line_interaction_type="downbranch"), True, 1e-10),
+        ("radfield_macroatom", dict(seed=4, n_packets=5000, n_shells=5, n_lines=300, line_interaction_type="macroatom"), True, 1e-8)):
+    prob = synthetic.make_problem(**args)
+    res = oracle.run(prob.packet_collection, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
+                     prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE, track_last_interaction=False)
+    g = prob.geometry
+    volume = 4.0 / 3.0 * np.pi * (g.r_outer**3 - g.r_inner**3)
+    t_sim = prob.packet_collection.time_of_simulation
+    eb = ref.EstimatorsBulk(res.j_estimator.copy(), res.nu_bar_estimator.copy())
+    el = ref.EstimatorsLine(res.j_blue_estimator.copy(), res.edotlu_estimator.copy())
+    out = ref.MCRadiationFieldPropertiesSolver(w_eps).solve(eb, el, Q(prob.time_explosion, "s"), Q(t_sim, "s"), volume,
+                                                            prob.opacity_state.line_list_nu, window)
+    st = out.dilute_blackbody_radiationfield_state
+    assert (res.j_blue_estimator == 0).any() and (res.j_blue_estimator != 0).any()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), problem_args=repr(args), detailed_optical_window=window, w_epsilon=w_eps,
+                        in_j_estimator=res.j_estimator, in_nu_bar_estimator=res.nu_bar_estimator,
+                        in_j_blue_estimator=res.j_blue_estimator, in_time_explosion=prob.time_explosion, in_time_of_simulation=t_sim,
+                        in_volume=volume, in_line_list_nu=prob.opacity_state.line_list_nu,
+                        t_radiative=np.asarray(st.temperature.value), dilution_factor=st.dilution_factor, j_blues=out.j_blues)
+    print(name, st.temperature.value[:3], st.dilution_factor[:3])
