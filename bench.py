@@ -82,6 +82,10 @@ def main():
                     help="packets of the drop-in boundary call timed after the steps (0: skip; default 1e7 capped by --packets)")
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="engine option (tardis_mc_set_option)")
+    ap.add_argument("--all-on-device", type=int, default=None, metavar="D",
+                    help="every rank uses GPU D instead of GPU LOCAL_RANK (tests of the N > 1 path on a one-GPU box)")
+    ap.add_argument("--dump-estimators", type=str, default=None, metavar="NPZ",
+                    help="rank 0 writes the job's (all-reduced) J, nu_bar and per-shell sums of j_blue / Edotlu of the last step")
     args = ap.parse_args()
 
     pg = distributed.init_from_env(backend="gloo")  # control plane only; the data-path collective is RCCL
@@ -107,7 +111,7 @@ def main():
     # opacities, geometry, configuration on the host (same on every rank); the packets never exist on the host
     prob = synthetic.make_problem(seed=1, n_packets=1, **kw)
 
-    eng = Engine(pg.local_rank)
+    eng = Engine(pg.local_rank if args.all_on_device is None else args.all_on_device)
     if args.variant is not None:
         eng.set_option("variant", args.variant)
     for o in args.option:
@@ -150,6 +154,16 @@ def main():
     last_ms = eng.last_propagate_ms()
     ktimes = eng.last_kernel_times()
     counters = eng.last_counters()
+
+    if args.dump_estimators:
+        r = eng.get_results(track_last_interaction=False)
+        arrays = [r.j_estimator, r.nu_bar_estimator, r.j_blue_estimator, r.edotlu_estimator]
+        if n_gpus > 1 and not rccl_ok:  # (with RCCL the resident estimators are the all-reduced ones already)
+            pg.sum_arrays_(arrays)
+        if pg.rank == 0:
+            np.savez(args.dump_estimators, j_estimator=arrays[0], nu_bar_estimator=arrays[1],
+                     j_blue_shell_sums=arrays[2].sum(axis=0), edotlu_shell_sums=arrays[3].sum(axis=0),
+                     j_blue_line_sums=arrays[2].sum(axis=1), rccl=np.array(bool(rccl_ok)))
 
     total_packets = float(P) * n_gpus * args.steps
     value = total_packets / elapsed

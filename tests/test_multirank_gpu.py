@@ -1,0 +1,51 @@
+"""The N > 1 path of bench.py on real hardware, as far as one GPU allows: two ranks (one process each, launched the way the
+driver launches them) share GPU 0.  RCCL refuses two ranks on one device, so the job takes bench.py's documented fall-back --
+the estimator arrays are summed through the control plane (gloo) -- which exercises everything else of the N > 1 path: the
+rendezvous, rank r drawing packets [r P, (r+1) P) of the 2 P-packet stream on the device, barriers, max-over-ranks timing.
+The summed estimators must equal those of ONE rank propagating all 2 P packets (results are partition-invariant up
+to the summation order)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path):
+    P = 100_000
+    common = ["--config", "2", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--boundary-packets", "0"]
+    two = tmp_path / "two.npz"
+    one = tmp_path / "one.npz"
+    line2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--packets", str(P), "--all-on-device", "0",
+                  "--dump-estimators", str(two)] + common)
+    line1 = _run([sys.executable, "bench.py", "--gpus", "1", "--packets", str(2 * P), "--dump-estimators", str(one)] + common)
+    assert line2["n_gpus"] == 2 and line2["scaling"] == "weak" and line2["config"]["packets_per_gpu"] == P
+    assert line2["value"] > 0 and line1["n_gpus"] == 1
+    assert "all-reduce" in line2["config"]["parallelism"]
+    a, b = np.load(two), np.load(one)
+    for k in ("j_estimator", "nu_bar_estimator", "j_blue_shell_sums", "edotlu_shell_sums", "j_blue_line_sums"):
+        assert_allclose(a[k], b[k], rtol=1e-10, err_msg=k)
+    assert np.all(a["j_estimator"] > 0)
