@@ -232,7 +232,9 @@ def measured_traffic(args, P: int, launches: int):
         d = json.load(open(path))
         if int(d.get("packets_per_gpu", -1)) != P:
             return None
-        return d.get("hbm_bytes_per_launch")
+        # (the PMC passes sum over the launches of a step; the split of a step into launches -- epochs -- depends on the log
+        # capacity, the traffic of the step does not)
+        return d["hbm_bytes_per_step"] / max(launches, 1)
     except Exception:
         return None
 

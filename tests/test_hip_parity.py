@@ -286,7 +286,7 @@ def test_baseline_config2_full_size(engine, oracle):
     engine.set_option("log_capacity", 60_000_000)
     _, _, eb2, el2, _, c2 = run_hip(engine, prob, track=False)
     assert engine.last_kernel_times()["launches"] >= 3
-    engine.set_option("log_capacity", 1_500_000_000)
+    engine.set_option("log_capacity", 2_500_000_000)
     assert np.array_equal(pc.output_nus, nus) and np.array_equal(pc.output_energies, ens)
     assert c1 == c2
     assert_allclose(eb2.mean_intensity_total, eb.mean_intensity_total, rtol=EST_RTOL)

@@ -13,6 +13,10 @@ P = int(float(sys.argv[1]))
 shape = dict(n_shells=20, n_lines=500_000, line_interaction_type="macroatom")
 if os.environ.get("EXP_SHAPE") == "config2":
     shape = dict(n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+if os.environ.get("EXP_SHAPE") == "config2v":
+    shape = dict(n_shells=20, n_lines=30_000, line_interaction_type="downbranch", n_vpackets=10)
+if os.environ.get("EXP_SHAPE") == "config5":
+    shape = dict(n_shells=100, n_lines=500_000, line_interaction_type="macroatom", n_vpackets=10)
 prob = synthetic.make_problem(seed=1, n_packets=1, **shape)
 eng = Engine(0)
 eng.set_geometry(prob.geometry, prob.time_explosion)
