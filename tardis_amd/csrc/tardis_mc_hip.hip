@@ -1113,7 +1113,13 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // group sweeps once the walk ran per lane on the compact tables and a call became epochs over one packet supply
     // (19.3 vs 13.4 Mpkt/s at 2e7 packets): the group sweeps' 280 instructions per 16-line step had become the bound.
     const bool prefer_lane_sweeps = !c.enable_full_relativity && !vpk;
-    int variant = ctx->variant >= 0 ? ctx->variant : ((vpk && c.number_of_vpackets > 32) ? 0 : (prefer_lane_sweeps ? 3 : 2));
+    // With v-packets the wave kernel's pooled volleys win where a v-packet crosses few shells and few lines (the tardis_example
+    // shape: 8.0 vs 5.2 Mpkt/s); on finer grids and longer line lists the group kernel -- every lane of a packet's group traces one
+    // v-packet of the volley, no speculation on the draw positions -- was measured 1.2x to 2.2x ahead
+    // (profiles/r02_vpacket_kernel_choice.txt).
+    const bool vpk_wave = vpk && ctx->n_shells <= 30 && ctx->n_lines <= 100000;
+    int variant = ctx->variant >= 0 ? ctx->variant
+                                    : ((vpk && c.number_of_vpackets > 32) ? 0 : (vpk ? (vpk_wave ? 2 : 1) : (prefer_lane_sweeps ? 3 : 2)));
     if (ctx->prob_negative && (variant == 2 || variant == 3)) variant = 1;  // (the wave kernel searches the monotone running sums)
     // Russian roulette with survivors (virtual_packet.py:221-232; the reference's SURVIVAL_PROBABILITY is 0 in every run, nothing
     // sets it): a surviving v-packet may play again in a later shell, so its draw count is unbounded, while the wave kernel's
