@@ -6,8 +6,9 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one Monte Carlo iteration of the hot path over one resident batch of synthetic packets: zero the
-estimators, propagate every packet of this rank's shard (HIP kernels; one `tardis_mc_propagate` call, which splits the
-batch into log-bounded chunks on two streams), and -- for N > 1 -- the one RCCL all-reduce of the estimator arrays
+estimators, propagate every packet of this rank's shard (HIP kernels; one `tardis_mc_propagate` call, which runs the
+grid over the whole batch in as many launches -- epochs -- as the line-visit log needs, the estimator passes of an epoch
+beside the next one), and -- for N > 1 -- the one RCCL all-reduce of the estimator arrays
 (J, nu_bar, j_blue, Edotlu, v-hist) that an outer plasma iteration needs.  Inputs (packets, opacity tables) are
 resident in HBM before the timed region.  Weak scaling: every rank owns `--packets` packets, so an N-GPU iteration
 propagates N x packets.
@@ -187,8 +188,10 @@ def main():
     if pg.rank == 0:
         # dominant kernel = the propagation kernel; its launches of one step are timed with HIP events on the streams they run on
         launches = max(ktimes["launches"], 1)
-        wave = args.variant in (None, 2, 3)
-        dominant = "propagate_wave_kernel" if wave else ("propagate_lane_kernel" if args.variant == 0 else "propagate_group_kernel")
+        variant = eng.last_variant()  # (the engine's automatic choice unless --variant was given)
+        wave = variant in (2, 3)
+        dominant = {0: "propagate_lane_kernel", 1: "propagate_group_kernel", 2: "propagate_wave_kernel (group sweeps)",
+                    3: "propagate_wave_kernel (lane sweeps)"}[variant]
         kernel_ms = ktimes["propagate_ms"] / launches
         # the dominant kernel's own algorithmic bytes (see algorithmic_bytes) over its HIP-event duration
         bytes_per_launch = algorithmic_bytes(counters, "propagate" if wave else "step") / launches

@@ -178,6 +178,9 @@ int tardis_mc_last_estimator_ms(TardisMcContext *ctx, double *out_ms);
 /* raw work counters of the last kernel launches (TARDIS_MC_CNT_*; after tardis_mc_formal_integral counters[0] is the number
  * of resonances crossed by all rays) */
 int tardis_mc_last_counters(TardisMcContext *ctx, int64_t out_counters[TARDIS_MC_N_COUNTERS]);
+/* Which propagation kernel the last tardis_mc_propagate ran (the "variant" option, or the automatic choice): 0 lane-per-packet,
+ * 1 group-per-packet, 2 wave-owner with group sweeps, 3 wave-owner with lane sweeps; -1 before the first call. */
+int tardis_mc_last_variant(TardisMcContext *ctx);
 /* Per-packet results of the resident packets + estimators (re-laid to [L,S]) to caller memory. */
 int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *result);
 

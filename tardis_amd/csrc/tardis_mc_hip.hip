@@ -158,6 +158,7 @@ struct TardisMcContext {
     double sum_seed_ms = 0.0, sum_prop_ms = 0.0, sum_post_ms = 0.0;
     int launches = 0;
     int log_sets = 2;
+    int last_variant = -1;  // kernel of the last propagate call (see tardis_mc_last_variant)
     int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
     // RCCL
     void *comm = nullptr;
@@ -1126,6 +1127,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // pooled volleys budget one roulette draw per v-packet -- such problems run on the group kernel
     if (vpk && c.survival_probability > 0.0 && (variant == 2 || variant == 3)) variant = 1;
     const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2 || variant == 3) && (!vpk || c.number_of_vpackets <= 32);
+    ctx->last_variant = cooperative ? ((variant == 3 && c.enable_full_relativity) ? 2 : variant) : 0;
 
     if (!cooperative) {
         // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment
@@ -1531,6 +1533,8 @@ int tardis_mc_last_counters(TardisMcContext *ctx, int64_t out_counters[TARDIS_MC
     out_counters[TARDIS_MC_CNT_PACKETS] = ctx->n_packets;
     return TARDIS_MC_OK;
 }
+
+int tardis_mc_last_variant(TardisMcContext *ctx) { return ctx ? ctx->last_variant : -1; }
 
 int tardis_mc_last_estimator_ms(TardisMcContext *ctx, double *out_ms)
 {

@@ -114,6 +114,10 @@ class Engine:
         self._check(self._L.tardis_mc_last_estimator_ms(self._h, C.byref(e)), "last_estimator_ms")
         return {"seed_ms": a.value, "propagate_ms": b.value, "launches": n.value, "estimator_ms": e.value}
 
+    def last_variant(self) -> int:
+        """Propagation kernel of the last propagate(): 0 lane, 1 group, 2 wave + group sweeps, 3 wave + lane sweeps."""
+        return int(self._L.tardis_mc_last_variant(self._h))
+
     def get_results(self, output_nus=None, output_energies=None, track_last_interaction=True,
                     want_line_estimators=True, vpacket_log_capacity=None) -> _abi.ResultBuffers:
         trackers = st.LastInteractionTrackers(self.n_packets) if track_last_interaction else None
