@@ -103,6 +103,7 @@ struct DeviceProblem {
 // Slim by-value argument block of the cooperative kernel: only what the inner loops touch stays in SGPRs; everything
 // used once per packet (inputs, outputs, tracker arrays, counters) is read through `cold` (a device copy of the full
 // DeviceProblem) at the point of use.
+struct WalkRec;
 struct GroupArgs {
     const DeviceProblem *cold;
     int n_shells, n_lines, n_trans;
@@ -120,7 +121,7 @@ struct GroupArgs {
     const double *cum_t, *trans_nu;
     // compact tables of the per-lane macro-atom walk (walk_tables.hpp; null unless the launch uses them)
     const unsigned short *cum16;  // [S][cum16_stride]
-    const uint2 *rec8;            // [compact transitions]
+    const struct WalkRec *rec16;  // [compact transitions]
     const int2 *quad_info;        // [compact transitions / 8]
     unsigned cum16_stride;
     double *jblue_t, *edot_t;

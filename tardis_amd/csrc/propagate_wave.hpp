@@ -707,7 +707,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         // trip of its own -- are rarely needed)
         refill(__ballot((ready || state == WS_NEED_TRACE || state == WS_WALK) && r_cnt <= RING - 4), seeded_states);
         int err = 0, type = 0, emit = -1, mb0 = 0, mb1 = 0;
-        double inv_new = 1.0, distance = 0.0;
+        double inv_new = 1.0, distance = 0.0, emit_nu_walk = 0.0;
         bool in_macro = false, interacted = false;
         bool want_volley = false;  // this lane's packet launches a volley of v-packets in this pass
         // a macro-atom walk that the previous pass left unfinished (the wave does not wait for its longest chains): the line
@@ -879,12 +879,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (in_macro) {
                     if (sel < 0) { err = ERR_MACRO_ATOM; in_macro = false; }
                     else {
-                        const uint2 rec = P.rec8[(unsigned)(mb0 + sel)];
-                        if (rec.y & WALK_EMIT) {
-                            emit = (int)rec.x;
+                        const WalkRec rec = P.rec16[(unsigned)(mb0 + sel)];
+                        if (rec.b & WALK_EMIT) {
+                            emit = (int)rec.a;
+                            emit_nu_walk = rec.nu;  // (the emission line's frequency travels with the record: no read of nu_line afterwards)
                             in_macro = false;
-                            if (rec.y & WALK_UNSUPPORTED) err = ERR_UNSUPPORTED;
-                        } else { mb0 = (int)rec.x; mb1 = (int)rec.y; }
+                            if (rec.b & WALK_UNSUPPORTED) err = ERR_UNSUPPORTED;
+                        } else { mb0 = (int)rec.a; mb1 = (int)rec.b; }
                     }
                 }
             }
@@ -994,8 +995,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         const bool carried = state == WS_WALK && in_macro;  // (set above, compact walk only)
         if (carried) in_macro = false;
         // downbranch (one jump over a short block)
-        bool have_emit_nu = false;
-        double emit_nu = 0.0;
+        bool have_emit_nu = P.cum16 != nullptr && emit >= 0 && !carried;  // (the compact walk brought the frequency along)
+        double emit_nu = emit_nu_walk;
         {
             bool searching = false;  // the first eight entries did not decide this lane's jump: 4-ary search in [lo, hi)
             int lo = 0, hi = 0;      // cum[j] <= event for all block entries j < lo; hi == mb1 or cum[hi] > event

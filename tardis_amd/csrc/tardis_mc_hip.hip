@@ -98,7 +98,7 @@ struct TardisMcContext {
     // opacity
     int n_lines = 0, n_trans = 0, n_levels = 0;
     DevBuf nu_line, tau_t, n_e, prob_t, cum_t, trans_nu, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec, bucket_first;
-    DevBuf cum16, rec8, quad_info, line_block_c;  // compact walk tables (walk_tables.hpp)
+    DevBuf cum16, rec16, quad_info, line_block_c;  // compact walk tables (walk_tables.hpp)
     unsigned cum16_stride = 0;
     bool have_walk_tables = false;
     int bucket_shift = 0, bucket_n = 0;
@@ -577,7 +577,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
     ctx->li_rec.release();
-    ctx->cum16.release(); ctx->rec8.release(); ctx->quad_info.release(); ctx->line_block_c.release();
+    ctx->cum16.release(); ctx->rec16.release(); ctx->quad_info.release(); ctx->line_block_c.release();
     ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
     if (ctx->suspended_host) (void)hipHostFree(ctx->suspended_host);
     for (hipEvent_t e : ctx->ev_post) if (e) (void)hipEventDestroy(e);
@@ -751,7 +751,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         const unsigned long long stride = (unsigned long long)tc + mc::WALK_SLACK;
         if (tc > 0 && stride * S < (1ull << 32) && tc < (1LL << 30)) {
             std::vector<int> qi(2 * (size_t)n_quads), lbc(2 * L, 0);
-            std::vector<unsigned> r8(2 * (size_t)tc + 4, 0u);  // (+ slack: a lane reads 16 bytes at an 8-byte record)
+            std::vector<mc::WalkRec> r16((size_t)tc + 1, mc::WalkRec{0u, 0u, 0.0});
             for (size_t b = 0; b < n_levels; ++b) {
                 const long long b0 = o->macro_block_edge_index[b], b1 = o->macro_block_edge_index[b + 1];
                 for (long long q = c0[b] / 8, k = b0; k < b1; ++q, k += 8) { qi[2 * q] = (int)k; qi[2 * q + 1] = (int)(b1 - k); }
@@ -760,13 +760,14 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
                     const int64_t tt = o->transition_type[k];
                     if (tt >= 0) {
                         const int64_t lvl = o->destination_level_id[k];
-                        r8[2 * c] = (unsigned)c0[lvl];
-                        r8[2 * c + 1] = (unsigned)(o->macro_block_edge_index[lvl + 1] - o->macro_block_edge_index[lvl]);
+                        r16[c].a = (unsigned)c0[lvl];
+                        r16[c].b = (unsigned)(o->macro_block_edge_index[lvl + 1] - o->macro_block_edge_index[lvl]);
                     } else if (tt == -1) {
-                        r8[2 * c] = (unsigned)o->transition_line_id[k];
-                        r8[2 * c + 1] = mc::WALK_EMIT;
+                        r16[c].a = (unsigned)o->transition_line_id[k];
+                        r16[c].b = mc::WALK_EMIT;
+                        r16[c].nu = o->line_list_nu[o->transition_line_id[k]];
                     } else
-                        r8[2 * c + 1] = mc::WALK_EMIT | mc::WALK_UNSUPPORTED;
+                        r16[c].b = mc::WALK_EMIT | mc::WALK_UNSUPPORTED;
                 }
             }
             for (size_t i = 0; i < L; ++i) {
@@ -775,7 +776,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
                 lbc[2 * i + 1] = (int)(o->macro_block_edge_index[lvl + 1] - o->macro_block_edge_index[lvl]);
             }
             if ((rc = upload(ctx, ctx->quad_info, qi.data(), qi.size()))) return rc;
-            if ((rc = upload(ctx, ctx->rec8, r8.data(), r8.size()))) return rc;
+            if ((rc = upload(ctx, ctx->rec16, r16.data(), r16.size()))) return rc;
             if ((rc = upload(ctx, ctx->line_block_c, lbc.data(), lbc.size()))) return rc;
             HIP_TRY(ctx, ctx->cum16.ensure((size_t)stride * S * sizeof(unsigned short)));
             HIP_TRY(ctx, hipMemsetAsync(ctx->cum16.p, 0xff, (size_t)stride * S * sizeof(unsigned short), ctx->stream));
@@ -1177,7 +1178,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         // cooperative group scan of the fp64 running sums, 128 the per-lane search in them (both for cross-checks)
         const bool compact_walk = wave_kernel && c.line_interaction_type == 2 && ctx->have_walk_tables && !(ctx->debug_flags & (128 | 8192));
         if (compact_walk) {
-            P.cum16 = ctx->cum16.as<unsigned short>(); P.rec8 = ctx->rec8.as<uint2>(); P.quad_info = ctx->quad_info.as<int2>();
+            P.cum16 = ctx->cum16.as<unsigned short>(); P.rec16 = ctx->rec16.as<mc::WalkRec>(); P.quad_info = ctx->quad_info.as<int2>();
             P.cum16_stride = ctx->cum16_stride;
             P.line_block = ctx->line_block_c.as<int2>();
         }

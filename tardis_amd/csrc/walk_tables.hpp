@@ -13,9 +13,9 @@
 //                       cum16 > x  =>  cum > xi          cum16 < x  =>  cum <= xi          (floor is monotone)
 //                   so only an entry with cum16 == x (2^-16 of the draws per entry) needs the fp64 sum: same decisions as the
 //                   reference, 2 bytes per transition instead of 8.  A block of <= 32 transitions is one 16..64-byte read.
-//   rec8[c]       = what the selected transition leads to, shell-independent: {c0, rows} of the destination level's block, or
-//                   {line id, EMIT} for an emission (transition type -1), or {0, UNSUPPORTED} for the reference's other
-//                   negative types (continuum processes, not part of the classic mode).
+//   rec16[c]      = what the selected transition leads to, shell-independent, one 16-byte read: {c0, rows} of the destination
+//                   level's block, or {line id, EMIT, nu of that line} for an emission (transition type -1), or
+//                   {0, UNSUPPORTED} for the reference's other negative types (continuum processes, not in the classic mode).
 //   quad_info[q]  = {original transition index of compact entry 8 q, entries from there to the end of its block}: maps a
 //                   compact index back to cum_t for the exact comparison.
 //   line_block_c[line] = {c0, rows} of the block the line activates.
@@ -26,6 +26,10 @@
 namespace mc {
 
 constexpr unsigned WALK_EMIT = 0x80000000u, WALK_UNSUPPORTED = 0x40000000u;
+struct __attribute__((aligned(16))) WalkRec {
+    unsigned a, b;  // internal transition: compact start and rows of the destination block; emission: line id, WALK_EMIT [| WALK_UNSUPPORTED]
+    double nu;      // emission: frequency of the line (line_emission, interaction_events.py:227-258, needs it next)
+};
 constexpr int WALK_WINDOW_QUADS = 4;   // 8-entry quads (16 bytes) a lane reads per jump
 constexpr int WALK_SLACK = 8 * WALK_WINDOW_QUADS;  // entries of slack at the end of every cum16 row
 
