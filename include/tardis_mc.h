@@ -151,8 +151,13 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
 /* Tunables.  name: "track_last_interaction" (0/1, default 1), "vpacket_log_capacity" (entries),
  * "variant" (kernel variant: -1 automatic, 0 lane-per-packet, 1 group-per-packet, 2 wave-owner with group sweeps, 3 wave-owner
  * with lane sweeps), "lane_sweep_min_active" / "lane_sweep_max_steps" (when variant 3 leaves its sweep phase),
+ * "walk_min_active" (macroatom walks are carried over to the next pass once this few lanes still walk; -1 never),
+ * "log_capacity" (line-visit records per epoch and buffer set of the wave-owner kernel; a call that logs more runs as several
+ * launches over one packet supply), "log_sets" (1: the estimator passes of an epoch run before the next
+ * epoch instead of beside it), "chunk_packets" (packets per launch of the group kernel), "waves_per_simd", "group_size",
  * "blocks_per_cu", "estimator_copies" (1..8 private j_blue/Edotlu copies),
- * "debug_flags" (profiling experiments only: 1 skips the j_blue/Edotlu atomics, 2 the J/nu_bar updates). */
+ * "debug_flags" (profiling experiments / cross-checks only: 1 skips the j_blue/Edotlu updates, 2 the J/nu_bar updates, 128
+ * walks the macro atom by a per-lane search in the fp64 running sums, 8192 by the cooperative group scan). */
 int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value);
 
 /* ---- staged API: inputs resident in HBM, kernels timed separately -------------------------------- */

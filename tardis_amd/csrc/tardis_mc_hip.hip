@@ -139,11 +139,10 @@ struct TardisMcContext {
     // wave kernel: chunks alternate between two buffer sets / streams, so that seeding and the estimator passes of one
     // chunk overlap the propagation of its neighbours
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], seeded_states2, next_packet2, wave_cold_dev;
+    hipEvent_t ev_join = nullptr;
+    DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], wave_cold_dev;
     DevBuf seed_chk[2], vp_scratch[2];  // (vp_scratch: per buffer set -- chunks on the two streams overlap)
     // wave kernel: word 397 of every packet's init_genrand sequence (lazy MT19937 seeding)
-    int pipeline_chunks = 1;  // >1: split a propagate call of the wave kernel into chunks on two streams (measured: a loss -- every chunk pays the drain of its last packets)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
     double traces_per_packet = 0.0;  // measured by the last propagate (sizes the line-visit log of the next one)
     double log_budget_per_packet = 128.0;  // log records reserved per packet
@@ -572,7 +571,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
         ctx->log_records[b].release(); ctx->log_keys[b].release(); ctx->log_cursor[b].release(); ctx->log_bins[b].release();
         ctx->log_sorted[b].release();
     }
-    ctx->seeded_states2.release(); ctx->next_packet2.release(); ctx->wave_cold_dev.release();
+    ctx->wave_cold_dev.release();
     ctx->seed_chk[0].release(); ctx->seed_chk[1].release(); ctx->vp_scratch[0].release(); ctx->vp_scratch[1].release();
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
@@ -587,7 +586,6 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     if (ctx->events_host) (void)hipHostFree(ctx->events_host);
     if (ctx->ev_events) (void)hipEventDestroy(ctx->ev_events);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -610,7 +608,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "lane_sweep_max_steps") ctx->ls_max_steps = (int)std::max<long long>(1, value);
     else if (n == "walk_min_active") ctx->walk_min_active = (int)std::max<long long>(-1, std::min<long long>(value, 63));
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
-    else if (n == "pipeline_chunks") ctx->pipeline_chunks = std::max(1, (int)value);
+    else if (n == "pipeline_chunks") {}  // (round 1: chunks on two streams; a call of the wave kernel now runs as epochs -- accepted, ignored)
     else if (n == "log_capacity") { ctx->log_capacity = std::max<long long>(0, value); ctx->log_capacity_user = true; }
     else if (n == "log_sets") ctx->log_sets = value == 1 ? 1 : 2;  // 1: the estimator passes of an epoch run before the next epoch, not beside it
     else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
@@ -1254,7 +1252,6 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 int prio_lo = 0, prio_hi = 0;  // (the estimator passes' stream: highest priority, their workgroups are dispatched first)
                 (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
                 HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_hi));
-                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
                 HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
             }
             for (int k = 0; k < 4; ++k)
