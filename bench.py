@@ -245,7 +245,9 @@ def measured_traffic(args, P: int, launches: int):
 def default_cpu_sample(kw: dict) -> int:
     """~10-30 s of CPU work on a 16-thread box: the C oracle runs ~5e3 packets/s/thread on the 5e5-line macroatom shape
     and ~2e5 on the tardis_example shape."""
-    heavy = kw["n_lines"] > 100_000 or kw["line_interaction_type"] == "macroatom" or kw.get("n_vpackets", 0) > 0
+    if kw.get("n_vpackets", 0) > 0:  # (~1e4 packets/s on 16 threads with ten v-packets per interaction)
+        return 100_000
+    heavy = kw["n_lines"] > 100_000 or kw["line_interaction_type"] == "macroatom"
     return 800_000 if heavy else 10_000_000
 
 

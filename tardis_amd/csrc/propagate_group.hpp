@@ -392,6 +392,8 @@ struct VpDraws {  // draws of ONE v-packet: position `first` (in doubles after t
     bool overflow;
 };
 
+constexpr int VP_SUM_BATCH = 16;  // optical depths a lane requests per round trip of a v-packet's per-shell sum
+
 template <bool FULL, int G>
 __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &rng, VpDraws &dr, double r, double mu, double nu,
                                         double &energy, int shell, int next_line, double &tau_out, unsigned &vvisits)
@@ -429,31 +431,61 @@ __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &r
                 kk = kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
                 e = max(P.bucket_first[kk], start + 1);
                 if (e > L - 1) e = L - 1;
-                // forward to the first line that stops, then back while the previous one stops as well
-                for (;;) {
-                    if (!distance_line<FULL>(nu, r, mu, comov_nu, e == L - 1, P.nu_line[(unsigned)e], t, d_line)) return ERR_MONTECARLO;
-                    if (d_boundary <= d_line || e == L - 1) break;
-                    ++e;
-                }
-                bool stops = d_boundary <= d_line;
-                while (e > start + 1) {
-                    double d_prev;
-                    if (!distance_line<FULL>(nu, r, mu, comov_nu, false, P.nu_line[(unsigned)(e - 1)], t, d_prev)) return ERR_MONTECARLO;
-                    if (!(d_boundary <= d_prev)) break;
-                    --e;
-                    stops = true;
+                // (lines after `start` cannot raise: the list is sorted, their nu_diff is larger than that of `start`)
+                auto stops_at = [&](int k) -> bool {
+                    double d;
+                    (void)distance_line<FULL>(nu, r, mu, comov_nu, k == L - 1, P.nu_line[(unsigned)k], t, d);
+                    return d_boundary <= d;
+                };
+                // a window of four lines around the bucket guess in ONE round trip (the walk below -- one dependent load per
+                // line -- only if the guess was further off)
+                const int w0 = max(e - 1, start + 1);
+                bool sw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sw[i] = stops_at(min(w0 + i, L - 1));
+                bool resolved = false, stops = false;
+                if (sw[0]) {
+                    if (w0 == start + 1) { e = w0; stops = true; resolved = true; }
+                    else e = w0;  // the first stopping line lies before the window
+                } else if (sw[1]) { e = min(w0 + 1, L - 1); stops = true; resolved = true; }
+                else if (sw[2]) { e = min(w0 + 2, L - 1); stops = true; resolved = true; }
+                else if (sw[3]) { e = min(w0 + 3, L - 1); stops = true; resolved = true; }
+                else e = min(w0 + 3, L - 1);  // beyond the window
+                if (!resolved) {
+                    // forward to the first line that stops, then back while the previous one stops as well
+                    for (;;) {
+                        if (stops_at(e) || e == L - 1) break;
+                        ++e;
+                    }
+                    stops = stops_at(e);
+                    while (e > start + 1) {
+                        if (!stops_at(e - 1)) break;
+                        --e;
+                        stops = true;
+                    }
                 }
                 if (!stops) e = L;  // (only with a NaN/huge boundary distance: the reference then sums every line)
             }
-            // serial-order sum of tau over [start, e): loads are independent of the adds, issue them four at a time
+            // serial-order sum of tau over [start, e): the loads are independent of the adds, so VP_SUM_BATCH of them are in flight
+            // per round trip (a shell crossing of the 5e5-line list passes ~40 lines: with four at a time the sum alone was a chain
+            // of ten dependent round trips)
             const double *__restrict__ trow = P.tau_t + row;
             int k = start;
             const int e_sum = min(e, L);
-            for (; k + 4 <= e_sum; k += 4) {
-                const double t0 = trow[(unsigned)k], t1 = trow[(unsigned)k + 1], t2 = trow[(unsigned)k + 2], t3 = trow[(unsigned)k + 3];
-                tau_shell += t0; tau_shell += t1; tau_shell += t2; tau_shell += t3;
+            for (; k + VP_SUM_BATCH <= e_sum; k += VP_SUM_BATCH) {
+                double tb[VP_SUM_BATCH];
+#pragma unroll
+                for (int q = 0; q < VP_SUM_BATCH; ++q) tb[q] = trow[(unsigned)(k + q)];
+#pragma unroll
+                for (int q = 0; q < VP_SUM_BATCH; ++q) tau_shell += tb[q];
             }
-            for (; k < e_sum; ++k) tau_shell += trow[(unsigned)k];
+            if (k < e_sum) {  // the rest (< VP_SUM_BATCH lines), again in one round trip; +0.0 where there is no line
+                double tb[VP_SUM_BATCH];
+#pragma unroll
+                for (int q = 0; q < VP_SUM_BATCH; ++q) tb[q] = (k + q < e_sum) ? trow[(unsigned)(k + q)] : 0.0;
+#pragma unroll
+                for (int q = 0; q < VP_SUM_BATCH; ++q) tau_shell += tb[q];
+            }
             vvisits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
             next_line = e;
         }
