@@ -1172,9 +1172,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         P.delta_nu = F.delta_nu; P.vhist = F.vhist;
         P.bucket_first = ctx->bucket_first.as<int>(); P.bucket_shift = ctx->bucket_shift; P.bucket_n = ctx->bucket_n;
         P.bucket_kmin = ctx->bucket_kmin;
-        // macroatom mode of the wave kernel: per-lane walk on the compact tables (walk_tables.hpp); debug flag 8192 keeps the
-        // cooperative group scan of the fp64 running sums, 128 the per-lane search in them (both for cross-checks)
-        const bool compact_walk = wave_kernel && c.line_interaction_type == 2 && ctx->have_walk_tables && !(ctx->debug_flags & (128 | 8192));
+        // macro-atom jumps of the wave kernel (macroatom chains and the single jump of downbranch alike): per-lane walk on the
+        // compact tables (walk_tables.hpp); debug flag 8192 keeps the cooperative group scan of the fp64 running sums (macroatom) /
+        // the fp64 search (downbranch), 128 the per-lane search in them (both for cross-checks)
+        const bool compact_walk = wave_kernel && c.line_interaction_type != 0 && ctx->have_walk_tables && !(ctx->debug_flags & (128 | 8192));
         if (compact_walk) {
             P.cum16 = ctx->cum16.as<unsigned short>(); P.rec16 = ctx->rec16.as<mc::WalkRec>(); P.quad_info = ctx->quad_info.as<int2>();
             P.cum16_stride = ctx->cum16_stride;
