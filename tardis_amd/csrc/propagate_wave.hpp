@@ -31,7 +31,8 @@ namespace mc {
 constexpr int WV_STATE_STRIDE = 624;  // words between the MT19937 states of two packets
 constexpr int WV_RING = 8, WV_RING_VPK = 16;  // look-ahead doubles per packet (power of two; a refill adds 4, so it needs r_cnt <= 4).  16 with 8-double
                             // refills was measured: fewer refill rounds, but the extra 4 KiB of LDS costs the 12th wave of the CU
-enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3, WS_WALK = 4 };  // WS_WALK: a macro-atom walk carried over to the next pass
+enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3, WS_WALK = 4, WS_VOLLEY = 5 };  // WS_WALK: a macro-atom walk carried over to the next pass;
+                                                                                                              // WS_VOLLEY: a round of the packet's volley is with the v-packet tracer (volley queue)
 constexpr int RES_PENDING = -1;
 constexpr int WV_RESERVE = 32;  // packets a wave reserves per atomic on the chunk's packet counter
 
@@ -65,6 +66,22 @@ struct __attribute__((aligned(16))) VpResult {
 constexpr int VP_ROUND = 6;  // v-packets of one packet per round of a pooled volley (5 and 8 were measured: no difference)
 static_assert(2 * VP_ROUND + 3 <= 16, "a round's mu and roulette draws, plus the 4 doubles of the refill that completes them, must fit WV_RING_VPK");
 
+// Volley queue (variant 4).  On fine grids a v-packet crosses tens of shells and a volley's v-packets differ widely in length,
+// so tracing them inside the wave that owns the packets leaves most lanes idle (23 of 64 busy on the 100-shell shape).  With the
+// queue the propagation kernel only REQUESTS a round of v-packets -- the packet at the interaction, the look-ahead draws of its
+// stream, the roulette predictor -- and suspends the lane; vpacket_trace_kernel, launched after it, traces the v-packets of all
+// requests of the grid, one lane per v-packet, every lane pulling its next v-packet from the global list the moment it
+// finishes one; the next launch of the propagation kernel commits the results in the reference's order (same validation of
+// the predicted draw positions as the pooled volleys) and goes on.  The arithmetic of a v-packet is vp_shell_step()'s either way.
+struct __attribute__((aligned(16))) VolleyRequest {
+    double r, mu, nu, energy;          // the parent packet at the interaction
+    int shell, next_line, vdone, cnt;  // v-packets of the volley already committed; draws[] holds cnt look-ahead doubles
+    unsigned pred_bits;
+    int pad0, pad1, pad2;
+    double draws[WV_RING_VPK];         // the parent's stream from its current position
+};
+constexpr int VQ_RESERVE = 256;  // items a tracer wave reserves per atomic
+
 // Kernel arguments.  Only what the sweep loop touches is passed by value (-> SGPRs); everything the event phase needs is
 // read through `cold` (a device copy) at the top of every pass, so that it does not occupy scalar registers -- and, once
 // those run out, VGPR lanes -- during the sweeps.
@@ -75,6 +92,7 @@ struct WaveHot {
     const int2 *line_block;           // lane sweep: macro-atom block of a line (null unless line_interaction_type != 0), requested as soon as a line stops the trace
     int ls_min_active, ls_max_steps;  // lane sweep: leave the sweep phase once this few lanes are still sweeping / after this many steps
     int walk_min_active;              // compact macro-atom walk: carry the walks over once this few lanes are still walking (-1: never)
+    int vq_min_active;                // volley queue: end the launch once this few lanes can still go on while others wait for the tracer
 };
 struct LaunchRec;
 // Suspended state of a lane / of a wave: a propagate call is a sequence of launches ("epochs") of the same grid over ONE
@@ -95,12 +113,16 @@ struct __attribute__((aligned(16))) LaneSave {
     unsigned rng_a, rng_b;
     int vseq;
     unsigned pred_bits;
+    int vdone, pad_v0, pad_v1, pad_v2;  // volley queue: v-packets of the running volley committed so far (state WS_VOLLEY)
     // a carried-over macro-atom walk (state WS_WALK) and the interaction it belongs to: sh.chi | sh.rcp_chi | sh.nu | sh.rcp_nu | sh.comov_nu
     double walk_inv_new, walk_block, trk_nu, trk_mu, trk_energy;
 };
 struct WaveSave {
     long long res_next, res_end;
     int exhausted, done;
+    // volley queue: the work counters of the wave's earlier launches (a call of thousands of launches would otherwise send
+    // thousands x waves x 7 atomics to the same seven words: ~1 ms per launch)
+    unsigned long long cnt[7];
 };
 struct WaveCold {
     GroupArgs P;
@@ -117,7 +139,14 @@ struct WaveCold {
     LaneSave *save;      // [waves * 64]
     WaveSave *wsave;     // [waves]
     int resume;
-    unsigned *suspended;  // number of waves this launch suspended (0: the call is complete)
+    unsigned *suspended;  // [0] number of waves this launch suspended (0: the call is complete); [1] those whose log region is full
+    // volley queue (null / 0 unless variant 4): requests [waves * 64], items (slot << 3 | v-packet of the round), counters
+    // {items, next item of the tracer}; log_continue: a resumed wave goes on appending to its log region (region_count)
+    VolleyRequest *vq_req;
+    unsigned *vq_items;
+    unsigned *vq_count;
+    int log_continue;
+    double *vq_jsave;  // [waves][2 * n_shells]: the waves' J / nu_bar partial sums between the launches of a volley-queue call
 };
 
 // One worker slot of a group: the trace it is sweeping (group-uniform values) and this lane's line of the current chunk.
@@ -518,7 +547,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         lds_geo[s] = W->P.r_inner[s]; lds_geo[H.n_shells + s] = W->P.r_outer[s]; lds_geo[2 * H.n_shells + s] = W->P.n_e[s];
     }
     const int lane = threadIdx.x;  // one wave per workgroup
-    for (int s = lane; s < 2 * H.n_shells; s += 64) lds_J[s] = 0.0;
+    {   // (volley queue: a wave keeps its partial sums from launch to launch and adds them to the estimators when it is done)
+        const double *js = (W->resume && W->vq_jsave) ? W->vq_jsave + (size_t)blockIdx.x * (size_t)(2 * H.n_shells) : nullptr;
+        for (int s = lane; s < 2 * H.n_shells; s += 64) lds_J[s] = js ? js[s] : 0.0;
+    }
 
     const int j = lane & (G - 1);
     const int group_lane0 = lane & ~(G - 1);
@@ -539,6 +571,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     int vseq = 0;  // v-packets emitted so far by this lane's packet
     unsigned pred_bits = 0;  // roulette predictor of the volleys: bit i = v-packet i of the last volley took a roulette draw
     unsigned long long vtraced_total = 0;
+    int vq_done = 0;        // volley queue: v-packets of the running volley committed so far
+    bool vq_fresh = false;  // volley queue: this lane's round was requested in THIS launch (its results come with the next one)
     int trk_count = 0, trk_boundary = 0;  // interactions_count, boundary crossings since the last interaction
     bool trk_any = false;
     bool exhausted = false;  // wave-uniform: the chunk has no more packets to reserve
@@ -640,6 +674,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     if (W->resume) {  // continue where the previous epoch suspended this wave
         const WaveSave ws = W->wsave[blockIdx.x];
         res_next = ws.res_next; res_end = ws.res_end; exhausted = ws.exhausted != 0;
+        if (W->log_continue) log_used = W->log.region_count[blockIdx.x];  // (volley queue: many short launches share one log buffer)
         if (ws.done) state = WS_DONE;
         else {
             const LaneSave &v = W->save[(size_t)blockIdx.x * 64 + lane];
@@ -655,12 +690,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             s_line = v.s_line; s_row = v.s_row;
             sh.res_info[lane] = v.res_info; sh.res_line[lane] = v.res_line; pre_blk = make_int2(v.pre_blk_x, v.pre_blk_y);
             sh.rng_a[lane] = v.rng_a; sh.rng_b[lane] = v.rng_b;
-            vseq = v.vseq; pred_bits = v.pred_bits;
+            vseq = v.vseq; pred_bits = v.pred_bits; vq_done = v.vdone;
             sh.chi[lane] = v.walk_inv_new; sh.rcp_chi[lane] = v.walk_block;
             sh.nu[lane] = v.trk_nu; sh.rcp_nu[lane] = v.trk_mu; sh.comov_nu[lane] = v.trk_energy;
         }
     }
-    bool suspended = false;
+    bool suspended = false, suspended_log = false;
     unsigned dbg_passes = 0;
 #ifdef TMC_SECTION_TIMERS  // profiling builds only: wall time of the sections of a pass, section (debug_flags >> 8) & 7 -> counters[7]
     unsigned long long sec_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -678,9 +713,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         uint32_t *const seeded_states = W->seeded_states;
         const long long chunk_first = W->chunk_first, chunk_count = W->chunk_count;
         double *const jb = P.jblue_t, *const ed = P.edot_t;
-        if (W->save && log.region_capacity > 0 && log_used + 64 > log.region_capacity) {
-            // this wave's region of the line-visit log is full: suspend the lanes as they are (every lane is at the top of a
-            // pass: a swept trace waiting for its event, a lane sweep in progress, or done) and leave the rest to the next epoch
+        const bool log_full = W->save && log.region_capacity > 0 && log_used + 64 > log.region_capacity && __ballot(state != WS_DONE) != 0ull;
+        bool vq_stop = false;
+        if (VPK && W->vq_items) {
+            // volley queue: lanes whose round is with the tracer cannot go on in this launch; once (nearly) all others have
+            // joined them the wave suspends -- the tracer runs between this launch and the next
+            const unsigned long long waiting = __ballot(state == WS_VOLLEY && vq_fresh);
+            const unsigned long long can = __ballot(state != WS_DONE && !(state == WS_VOLLEY && vq_fresh));
+            vq_stop = waiting != 0ull && __popcll(can) <= H.vq_min_active;
+        }
+        if (log_full || vq_stop) {
+            // this wave's region of the line-visit log is full (or its lanes wait for the v-packet tracer): suspend the lanes as
+            // they are (every lane is at the top of a pass: a swept trace waiting for its event, a lane sweep in progress, a
+            // requested volley round, or done) and leave the rest to the next epoch
+            suspended_log = log_full;
             LaneSave v;
             v.r = p.r; v.mu = p.mu; v.nu = p.nu; v.energy = p.energy; v.dop = dop;
             v.s_tau = s_tau; v.s_tau_event = s_tau_event; v.s_kp = s_kp; v.s_xb = s_xb;
@@ -694,7 +740,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             v.s_line = s_line; v.s_row = s_row;
             v.res_info = sh.res_info[lane]; v.res_line = sh.res_line[lane]; v.pre_blk_x = pre_blk.x; v.pre_blk_y = pre_blk.y;
             v.rng_a = sh.rng_a[lane]; v.rng_b = sh.rng_b[lane];
-            v.vseq = vseq; v.pred_bits = pred_bits;
+            v.vseq = vseq; v.pred_bits = pred_bits; v.vdone = vq_done; v.pad_v0 = v.pad_v1 = v.pad_v2 = 0;
             v.walk_inv_new = sh.chi[lane]; v.walk_block = sh.rcp_chi[lane];
             v.trk_nu = sh.nu[lane]; v.trk_mu = sh.rcp_nu[lane]; v.trk_energy = sh.comov_nu[lane];
             W->save[(size_t)blockIdx.x * 64 + lane] = v;
@@ -1140,10 +1186,60 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         if (VPK) {
             // ---- trace_vpacket_volley (virtual_packet.py:248-386): all lanes with a volley trace their i-th v-packet together
             const int n_v = (int)P.n_vpackets;
-            bool in_volley = want_volley && state == WS_NEED_TRACE && !(p.nu < P.spawn_start || p.nu > P.spawn_end) && n_v > 0;
+            int verr = 0;
+            const DeviceProblem *C = &W->D;
+            // the owner validates and commits the v-packets of a round in order (both volley paths)
+            auto commit_round = [&](const VpResult *res, const int n_round, int &vdone) {
+                bool valid = true;
+                int n_ok = 0, consumed = 0;
+                unsigned obs = 0;
+                for (int sl = 0; sl < n_round; ++sl) {
+                    const VpResult r = res[sl];
+                    vtraced_total += (unsigned)r.visits;
+                    if (r.used > 0) obs |= 1u << sl;  // learn from every trace of the round, committed or not
+                    if (valid) {
+                        if (r.err) { verr = r.err; valid = false; }
+                        else {
+                            ++vcount;
+                            vvisits_total += (unsigned)r.visits;
+                            // add_vpacket_collection_to_histogram (modes/montecarlo_transport.py:166-195)
+                            if (!(r.nu < P.grid0 || r.nu > P.grid_last)) {
+                                const long long idx = (long long)floor((r.nu - P.grid0) / P.delta_nu);
+                                atomic_add_f64(&P.vhist[idx], r.energy);
+                            }
+                            if (C->vlog_count) {
+                                const unsigned long long slot = atomicAdd(C->vlog_count, 1ull);
+                                if ((long long)slot < C->vlog_capacity) {
+                                    C->vlog_packet[slot] = chunk_first + pkt; C->vlog_seq[slot] = vseq;
+                                    C->vlog_nu[slot] = r.nu; C->vlog_energy[slot] = r.energy; C->vlog_mu[slot] = r.mu0; C->vlog_r[slot] = p.r;
+                                }
+                            }
+                            ++vseq;
+                            ++n_ok;
+                            consumed += 1 + r.used;
+                            // it started from the right stream position itself; the items after it did only if it
+                            // consumed what was predicted
+                            if (r.used != (int)((pred_bits >> (vdone + sl)) & 1u)) valid = false;
+                        }
+                    }
+                }
+                const unsigned seen = (1u << n_round) - 1u;
+                pred_bits = (pred_bits & ~(seen << vdone)) | (obs << vdone);
+                r_head = (r_head + consumed) & (RING - 1);
+                r_cnt -= consumed;
+                draws += (unsigned)consumed;
+                vdone += n_ok;
+            };
+            // volley queue: the round this lane requested in the previous launch has come back from the tracer
+            bool cont_volley = false;  // ... and the queue has been switched off since (the drain of a call): the rest of the volley is pooled
+            if (state == WS_VOLLEY && !vq_fresh) {
+                commit_round(W->vp_scratch + ((size_t)blockIdx.x * 64 + lane) * VP_ROUND, min(VP_ROUND, n_v - vq_done), vq_done);
+                if (verr || vq_done == n_v) state = WS_NEED_TRACE;  // the volley is complete: on to the next trace
+                else if (!W->vq_items) { state = WS_NEED_TRACE; cont_volley = true; }
+            }
+            bool in_volley = cont_volley || (want_volley && state == WS_NEED_TRACE && !(p.nu < P.spawn_start || p.nu > P.spawn_end) && n_v > 0);
             double mu_min = 0.0, beta_inner = 0.0, mu_bin = 0.0, r_dop = 1.0;
             bool on_inner = false;
-            int verr = 0;
             if (in_volley) {
                 const double r_in0 = P.r_inner[0];
                 if (p.r > r_in0) {
@@ -1161,7 +1257,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 mu_bin = (1.0 - mu_min) / (double)n_v;
                 r_dop = doppler_factor<FULL>(p.r / t, p.mu);
             }
-            const DeviceProblem *C = &W->D;
             // Pooled volley.  The v-packets of ALL volleys of the wave are work items for ALL 64 lanes, so a packet deep in
             // the ejecta (many shells per v-packet) does not make the lanes of shallow packets wait.  The n_v mu-draws and
             // the Russian-roulette draws come from the parent's stream in sequence, so an item reads its draws at the
@@ -1169,9 +1264,46 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             // optical depth to first order -- the group kernel's predictor); the owner lane then commits its items in
             // order up to and including the first one whose draw consumption differs from the prediction, and the rest is
             // traced again in the next round from the corrected stream position.
+            if (W->vq_items) {
+                // ---- volley queue: commit the round that came back from the tracer, request the next one (see VolleyRequest)
+                const size_t slot = (size_t)blockIdx.x * 64 + lane;
+                if (in_volley) vq_done = 0;  // a new volley
+                const bool ask = !verr && (in_volley || (state == WS_VOLLEY && !vq_fresh));  // (or the next round of a running one)
+                const int n_round = ask ? min(VP_ROUND, n_v - vq_done) : 0;
+                for (;;) {  // one mu draw and one roulette draw per v-packet of the round must be in the ring
+                    const unsigned long long need = __ballot(ask && r_cnt < 2 * n_round);
+                    if (!need) break;
+                    refill(need, seeded_states);
+                }
+                int incl = n_round;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int up = __shfl_up(incl, off);
+                    if (lane >= off) incl += up;
+                }
+                const int n_items = __shfl(incl, 63);
+                if (n_items > 0) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(W->vq_count, (unsigned)n_items);
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    if (ask) {
+                        VolleyRequest rq;
+                        rq.r = p.r; rq.mu = p.mu; rq.nu = p.nu; rq.energy = p.energy;
+                        rq.shell = p.shell; rq.next_line = p.next_line_id; rq.vdone = vq_done; rq.cnt = r_cnt;
+                        rq.pred_bits = pred_bits; rq.pad0 = rq.pad1 = rq.pad2 = 0;
+#pragma unroll
+                        for (int q = 0; q < WV_RING_VPK; ++q) rq.draws[q] = ring[((r_head + q) & (RING - 1)) * 64 + lane];
+                        W->vq_req[slot] = rq;
+                        unsigned *it = W->vq_items + (base + (unsigned)(incl - n_round));
+                        for (int sl = 0; sl < n_round; ++sl) it[sl] = ((unsigned)slot << 3) | (unsigned)sl;
+                        state = WS_VOLLEY;
+                        vq_fresh = true;
+                    }
+                }
+            } else {
             VpResult *vres = W->vp_scratch + (size_t)blockIdx.x * (64 * VP_ROUND);
             unsigned short *items = reinterpret_cast<unsigned short *>(sh.nu);  // [64 * VP_ROUND] over sh.nu | sh.rcp_nu (idle now)
-            int vdone = 0;  // v-packets of this lane's volley committed so far
+            int vdone = cont_volley ? vq_done : 0;  // v-packets of this lane's volley committed so far
             while (__ballot(in_volley)) {
                 const int n_round = in_volley ? min(VP_ROUND, n_v - vdone) : 0;
                 for (;;) {  // one mu draw and one roulette draw per v-packet of the round must be in the ring
@@ -1262,47 +1394,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (in_volley) {
-                    bool valid = true;
-                    int n_ok = 0, consumed = 0;
-                    unsigned obs = 0;
-                    for (int sl = 0; sl < n_round; ++sl) {
-                        const VpResult r = vres[item0 + sl];
-                        vtraced_total += (unsigned)r.visits;
-                        if (r.used > 0) obs |= 1u << sl;  // learn from every trace of the round, committed or not
-                        if (valid) {
-                            if (r.err) { verr = r.err; valid = false; }
-                            else {
-                                ++vcount;
-                                vvisits_total += (unsigned)r.visits;
-                                // add_vpacket_collection_to_histogram (modes/montecarlo_transport.py:166-195)
-                                if (!(r.nu < P.grid0 || r.nu > P.grid_last)) {
-                                    const long long idx = (long long)floor((r.nu - P.grid0) / P.delta_nu);
-                                    atomic_add_f64(&P.vhist[idx], r.energy);
-                                }
-                                if (C->vlog_count) {
-                                    const unsigned long long slot = atomicAdd(C->vlog_count, 1ull);
-                                    if ((long long)slot < C->vlog_capacity) {
-                                        C->vlog_packet[slot] = chunk_first + pkt; C->vlog_seq[slot] = vseq;
-                                        C->vlog_nu[slot] = r.nu; C->vlog_energy[slot] = r.energy; C->vlog_mu[slot] = r.mu0; C->vlog_r[slot] = p.r;
-                                    }
-                                }
-                                ++vseq;
-                                ++n_ok;
-                                consumed += 1 + r.used;
-                                // it started from the right stream position itself; the items after it did only if it
-                                // consumed what was predicted
-                                if (r.used != (int)((pred_bits >> (vdone + sl)) & 1u)) valid = false;
-                            }
-                        }
-                    }
-                    const unsigned seen = (1u << n_round) - 1u;
-                    pred_bits = (pred_bits & ~(seen << vdone)) | (obs << vdone);
-                    r_head = (r_head + consumed) & (RING - 1);
-                    r_cnt -= consumed;
-                    draws += (unsigned)consumed;
-                    vdone += n_ok;
+                    commit_round(vres + item0, n_round, vdone);
                     if (verr || vdone == n_v) in_volley = false;
                 }
+            }
             }
             if (verr) {  // the reference raises: the packet ends with the error code
                 const long long i = chunk_first + pkt;
@@ -1485,17 +1580,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     }
 
     if (lane == 0 && W->log.region_capacity > 0) W->log.region_count[blockIdx.x] = min(log_used, W->log.region_capacity);
-    if (lane == 0 && W->wsave) {
-        WaveSave ws;
-        ws.res_next = res_next; ws.res_end = res_end; ws.exhausted = exhausted ? 1 : 0; ws.done = suspended ? 0 : 1;
-        W->wsave[blockIdx.x] = ws;
-        if (suspended) atomicAdd(W->suspended, 1u);
-    }
     const DeviceProblem *C = &W->D;
-    for (int s = lane; s < H.n_shells; s += 64) {
-        if (lds_J[s] != 0.0) atomic_add_f64(&C->J[s], lds_J[s]);
-        if (lds_nubar[s] != 0.0) atomic_add_f64(&C->nubar[s], lds_nubar[s]);
+    const bool keep = suspended && W->vq_jsave != nullptr;  // volley queue: partial sums and counters stay with the wave
+    if (W->vq_jsave) {
+        double *js = W->vq_jsave + (size_t)blockIdx.x * (size_t)(2 * H.n_shells);
+        for (int s = lane; s < 2 * H.n_shells; s += 64) js[s] = keep ? lds_J[s] : 0.0;
     }
+    if (!keep)
+        for (int s = lane; s < H.n_shells; s += 64) {
+            if (lds_J[s] != 0.0) atomic_add_f64(&C->J[s], lds_J[s]);
+            if (lds_nubar[s] != 0.0) atomic_add_f64(&C->nubar[s], lds_nubar[s]);
+        }
     // counters: wave-reduce, one atomic each
     unsigned long long v = (LS || j == 0) ? visits : 0ull;  // group sweeps: group-uniform, count once per group
     unsigned long long e = events, m = macro, d = draws, vv = vvisits_total, vc = vcount, vt = vtraced_total;
@@ -1504,11 +1599,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         vv += __shfl_down(vv, off); vc += __shfl_down(vc, off); vt += __shfl_down(vt, off);
     }
     if (lane == 0) {
-        atomicAdd(&C->counters[0], v);
-        atomicAdd(&C->counters[1], e);
-        atomicAdd(&C->counters[2], m);
-        atomicAdd(&C->counters[5], d);
-        if (VPK) { atomicAdd(&C->counters[3], vv); atomicAdd(&C->counters[4], vc); atomicAdd(&C->counters[7], vt); }
+        unsigned long long cn[7] = {v, e, m, d, vv, vc, vt};
+        if (W->wsave) {
+            WaveSave ws;
+            ws.res_next = res_next; ws.res_end = res_end; ws.exhausted = exhausted ? 1 : 0; ws.done = suspended ? 0 : 1;
+            if (W->vq_jsave && W->resume) {
+                const WaveSave &old = W->wsave[blockIdx.x];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) cn[k] += old.cnt[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k) ws.cnt[k] = keep ? cn[k] : 0ull;
+            W->wsave[blockIdx.x] = ws;
+            if (suspended) atomicAdd(W->suspended, 1u);
+            if (suspended_log) atomicAdd(W->suspended + 1, 1u);
+        }
+        if (!keep) {
+            if (cn[0]) atomicAdd(&C->counters[0], cn[0]);
+            if (cn[1]) atomicAdd(&C->counters[1], cn[1]);
+            if (cn[2]) atomicAdd(&C->counters[2], cn[2]);
+            if (cn[3]) atomicAdd(&C->counters[5], cn[3]);
+            if (VPK) {
+                if (cn[4]) atomicAdd(&C->counters[3], cn[4]);
+                if (cn[5]) atomicAdd(&C->counters[4], cn[5]);
+                if (cn[6]) atomicAdd(&C->counters[7], cn[6]);
+            }
+        }
         if (H.debug_flags & 16) atomicAdd(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
         if (H.debug_flags & 32) atomicAdd(&C->counters[7], (unsigned long long)dbg_passes);
 #ifdef TMC_SECTION_TIMERS
@@ -1519,6 +1635,124 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             atomicAdd(&C->counters[7], tsel);
         }
 #endif
+    }
+}
+
+// ---- volley queue: the v-packet tracer (see VolleyRequest).  One lane per v-packet; a lane that finishes takes the next item
+// of the launch-wide list (a wave reserves VQ_RESERVE items per atomic), so all 64 lanes of every wave trace until the list is
+// empty -- whatever the lengths of the v-packets.  Launch of the v-packet: trace_vpacket_volley (virtual_packet.py:248-386), the
+// same operations as the pooled volleys of propagate_wave_kernel; one shell crossing per iteration: vp_shell_step.
+template <bool FULL>
+__global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__restrict__ W)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double *geo = reinterpret_cast<double *>(lds_raw);  // r_inner | r_outer | n_e
+    const GroupArgs &P = W->P;
+    const int S = P.n_shells;
+    const int lane = threadIdx.x;
+    for (int s = lane; s < S; s += 64) { geo[s] = P.r_inner[s]; geo[S + s] = P.r_outer[s]; geo[2 * S + s] = P.n_e[s]; }
+    __syncthreads();
+    const unsigned n_items = W->vq_count[0];
+    const int n_v = (int)P.n_vpackets;
+    const double t = P.t_exp;
+    const double r_in0 = geo[0];
+    unsigned res_next = 0, res_end = 0;  // wave-uniform: reserved items not yet handed out
+    bool exhausted = n_items == 0;
+    bool tracing = false;
+    unsigned my_slot = 0;
+    int my_sl = 0, w_q = 0, w_used = 0, w_avail = 0;
+    unsigned my_visits = 0;
+    VpState vs;
+    double v_rcp_nu = 0.0;
+    bool v_fast = false;
+    vs.r = vs.mu = vs.nu = vs.energy = vs.tau = vs.mu0 = 0.0; vs.shell = 0; vs.next_line = 0;
+    for (;;) {
+        const unsigned long long free_l = __ballot(!tracing);
+        bool take = false;
+        unsigned my_item = 0;
+        if (free_l) {
+            if (res_next == res_end && !exhausted) {
+                unsigned b = 0;
+                if (lane == 0) b = atomicAdd(W->vq_count + 1, (unsigned)VQ_RESERVE);
+                b = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= n_items) exhausted = true;
+                else { res_next = b; res_end = min(b + (unsigned)VQ_RESERVE, n_items); }
+            }
+            const int n_take = min(__popcll(free_l), (int)(res_end - res_next));
+            const int rank = __popcll(free_l & ((1ull << lane) - 1ull));
+            take = !tracing && rank < n_take;
+            my_item = res_next + (unsigned)rank;
+            res_next += (unsigned)n_take;
+        }
+        if (!__ballot(tracing || take)) {
+            if (exhausted) break;
+            continue;
+        }
+        if (take) {
+            const unsigned it = W->vq_items[my_item];
+            my_slot = it >> 3; my_sl = (int)(it & 7u);
+            const VolleyRequest *rq = W->vq_req + my_slot;
+            const double f_r = rq->r, f_mu = rq->mu, f_nu = rq->nu, f_energy = rq->energy;
+            const int f_vdone = rq->vdone;
+            const unsigned f_pred = rq->pred_bits;
+            // the frame of the volley (:262-300), as the propagation kernel computes it for its pooled volleys
+            double mu_min = 0.0, beta_inner = 0.0;
+            bool on_inner = false;
+            if (f_r > r_in0) {
+                const double r_inner_over_r = r_in0 / f_r;
+                mu_min = -sqrt(1 - r_inner_over_r * r_inner_over_r);
+                if (FULL) mu_min = aberration_lf_to_cmf(f_r, t, mu_min);
+            } else {
+                on_inner = true;
+                if (FULL) {
+                    const double inv_c = 1 / C_LIGHT;
+                    const double inv_t = 1 / t;
+                    beta_inner = r_in0 * inv_t * inv_c;
+                }
+            }
+            const double mu_bin = (1.0 - mu_min) / (double)n_v;
+            const double r_dop = doppler_factor<FULL>(f_r / t, f_mu);
+            const int i = f_vdone + my_sl;  // index of the v-packet in its volley
+            const unsigned before = (f_pred >> f_vdone) & ((1u << my_sl) - 1u);  // predicted roulette draws of the round's earlier v-packets
+            const int q = my_sl + __popc(before);
+            const double xi = rq->draws[q];
+            w_q = q + 1; w_used = 0; w_avail = rq->cnt;
+            double v_mu = mu_min + (double)i * mu_bin + xi * mu_bin;
+            double weight;
+            if (on_inner) {
+                if (!FULL) weight = 2 * v_mu / (double)n_v;
+                else weight = 2 * (v_mu + beta_inner) / (2 * beta_inner + 1) / (double)n_v;
+            } else
+                weight = (1 - mu_min) / (double)(2 * n_v);
+            if (FULL) v_mu = aberration_cmf_to_lf(f_r, t, v_mu);
+            const double v_dop = doppler_factor<FULL>(f_r / t, v_mu);
+            const double ratio = r_dop / v_dop;
+            vs.r = f_r; vs.mu = v_mu; vs.mu0 = v_mu;  // the log records the (aberrated) launch direction (:337-340,375)
+            vs.nu = f_nu * ratio;
+            v_rcp_nu = 1.0 / vs.nu;
+            v_fast = mid_range(vs.nu);
+            vs.energy = f_energy * weight * ratio;
+            vs.tau = 0.0; vs.shell = rq->shell; vs.next_line = rq->next_line;
+            my_visits = 0;
+            tracing = true;
+        }
+        if (tracing) {
+            const double *dr = W->vq_req[my_slot].draws;
+            auto wdraw = [&]() {
+                const double d = dr[w_q + w_used];
+                ++w_used;
+                return d;
+            };
+            int draws_left = w_avail - (w_q + w_used);
+            const int st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, v_rcp_nu, v_fast, geo, my_visits);
+            if (st != 0) {
+                VpResult r;
+                r.nu = vs.nu; r.energy = st == 1 ? vs.energy * mcm::exp(-vs.tau) : 0.0; r.mu0 = vs.mu0;
+                r.used = w_used; r.visits = (int)my_visits; r.err = st < 0 ? st : 0; r.pad = 0;
+                W->vp_scratch[(size_t)my_slot * VP_ROUND + my_sl] = r;
+                tracing = false;
+            }
+        }
     }
 }
 

@@ -151,6 +151,9 @@ struct TardisMcContext {
     std::vector<mc::WaveCold> wave_cold_host;
     // wave kernel: a propagate call is a sequence of epochs over one packet supply (LaneSave, propagate_wave.hpp)
     DevBuf lane_save, wave_save, suspended_dev;
+    DevBuf vq_req, vq_items, vq_count, vq_jsave;  // volley queue (variant 4, propagate_wave.hpp: VolleyRequest)
+    long long vq_min_items = -1;  // switch the queue off for the rest of a call once a launch requests fewer v-packets (-1: automatic)
+    int vq_min_active = 8, vq_oversubscribe = 4, vq_tracer_waves_per_simd = 6;
     unsigned *suspended_host = nullptr;  // pinned
     hipEvent_t ev_post[4] = {nullptr, nullptr, nullptr, nullptr};  // start / end of the estimator passes on log buffer set 0 / 1
     bool wave_epoch_mode = false, post_pending[2] = {false, false}, prop_pending = false;
@@ -264,7 +267,8 @@ __global__ void debug_eval_kernel(int op, const double *x, const double *y, doub
 //        2 fp64 atomic add, 16 consecutive doubles per 16-lane group, agent scope; 3 same, workgroup scope/XCD slice;
 //        4 random 8-byte loads; 5 16-lane-coalesced 8-byte loads;
 //        6..9 every lane reads its own random, naturally aligned block of 16 / 32 / 64 / 128 bytes (dwordx4 loads);
-//        10 dependent chain: the address of a lane's next random 8-byte load comes out of the loaded value (latency)
+//        10 dependent chain: the address of a lane's next random 8-byte load comes out of the loaded value (latency);
+//        11 / 12 lane-private vs quad-shared 64-byte blocks (see below)
 __global__ void microbench_kernel(int which, double *table, long long n, int iters, double *sink)
 {
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -286,6 +290,32 @@ __global__ void microbench_kernel(int which, double *table, long long n, int ite
             for (int q = 0; q < 8; ++q) if (q < quads) v[q] = b[q];
 #pragma unroll
             for (int q = 0; q < 8; ++q) if (q < quads) acc += v[q].x + v[q].y;
+        }
+    } else if (which == 11 || which == 12) {
+        // 11: every lane reads its own random 64-byte block with four 16-byte loads (the lane sweeps' pattern);
+        // 12: the same blocks, but the four lanes of a quad read ONE block per instruction, lane j its j-th 16 bytes, four
+        //     instructions for the quad's four blocks (same bytes, same lines; fewer distinct lines per instruction)
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const unsigned long long n_blocks = (unsigned long long)n / 8ull;
+        const int lane = threadIdx.x & 63, j = lane & 3;
+        for (int it = 0; it < iters; ++it) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            const unsigned long long mine = (st >> 20) % n_blocks;
+            v2d v[4];
+            if (which == 11) {
+                const v2d *b = reinterpret_cast<const v2d *>(table) + mine * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = b[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, (lane & ~3) + q, 64), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), (lane & ~3) + q, 64);
+                    const unsigned long long blk = ((unsigned long long)hi << 32) | lo;
+                    v[q] = (reinterpret_cast<const v2d *>(table) + blk * 4)[j];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += v[q].x + v[q].y;
         }
     } else if (which == 10) {
         unsigned long long r = st >> 20;
@@ -578,6 +608,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     ctx->li_rec.release();
     ctx->cum16.release(); ctx->rec16.release(); ctx->quad_info.release(); ctx->line_block_c.release();
     ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
+    ctx->vq_req.release(); ctx->vq_items.release(); ctx->vq_count.release(); ctx->vq_jsave.release();
     if (ctx->suspended_host) (void)hipHostFree(ctx->suspended_host);
     for (hipEvent_t e : ctx->ev_post) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
@@ -606,6 +637,10 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
     else if (n == "lane_sweep_min_active") ctx->ls_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "lane_sweep_max_steps") ctx->ls_max_steps = (int)std::max<long long>(1, value);
+    else if (n == "vq_oversubscribe") ctx->vq_oversubscribe = (int)std::max<long long>(1, std::min<long long>(value, 64));
+    else if (n == "vq_tracer_waves_per_simd") ctx->vq_tracer_waves_per_simd = (int)std::max<long long>(1, std::min<long long>(value, 16));
+    else if (n == "vq_min_items") ctx->vq_min_items = value;
+    else if (n == "vq_min_active") ctx->vq_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "walk_min_active") ctx->walk_min_active = (int)std::max<long long>(-1, std::min<long long>(value, 63));
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
     else if (n == "pipeline_chunks") {}  // (round 1: chunks on two streams; a call of the wave kernel now runs as epochs -- accepted, ignored)
@@ -1124,8 +1159,12 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // Russian roulette with survivors (virtual_packet.py:221-232; the reference's SURVIVAL_PROBABILITY is 0 in every run, nothing
     // sets it): a surviving v-packet may play again in a later shell, so its draw count is unbounded, while the wave kernel's
     // pooled volleys budget one roulette draw per v-packet -- such problems run on the group kernel
-    if (vpk && c.survival_probability > 0.0 && (variant == 2 || variant == 3)) variant = 1;
-    const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2 || variant == 3) && (!vpk || c.number_of_vpackets <= 32);
+    if (vpk && c.survival_probability > 0.0 && (variant == 2 || variant == 3 || variant == 4)) variant = 1;
+    // variant 4: the wave kernel with the volley queue (v-packets traced by vpacket_trace_kernel between its launches); without
+    // v-packets there is nothing to queue
+    if (variant == 4 && !vpk) variant = prefer_lane_sweeps ? 3 : 2;
+    if (ctx->prob_negative && variant == 4) variant = 1;
+    const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2 || variant == 3 || variant == 4) && (!vpk || c.number_of_vpackets <= 32);
     ctx->last_variant = cooperative ? ((variant == 3 && c.enable_full_relativity) ? 2 : variant) : 0;
 
     if (!cooperative) {
@@ -1146,7 +1185,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     } else {
         // variant 1: group kernel, chunked (MT19937 states are seeded per chunk by a lane-per-packet kernel);
         // variants 2 / 3: wave-owner kernel, one packet supply for the whole call, launched in epochs (see LaneSave)
-        const bool wave_kernel = variant == 2 || variant == 3;
+        const bool wave_kernel = variant == 2 || variant == 3 || variant == 4;
+        const bool vq = variant == 4;
         ctx->problem_host = make_device_problem(ctx);
         const mc::DeviceProblem &F = ctx->problem_host;
         HIP_TRY(ctx, ctx->problem_dev.ensure(sizeof(mc::DeviceProblem)));
@@ -1211,7 +1251,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 #undef TMC_PICKW2
 #undef TMC_PICKW
             const long long n = ctx->n_packets;
-            const int waves = (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, (long long)cus * wave_waves_per_cu));
+            // (volley queue: more waves than the chip holds at once -- a wave that suspends frees its slot, and the more packets are
+            // in flight the more v-packets every tracer launch has to spread over its lanes)
+            const int waves = (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, (long long)cus * wave_waves_per_cu * (vq ? ctx->vq_oversubscribe : 1)));
             // ---- the line-visit log (estimator_log.hpp): two buffer sets, one region per wave; an epoch ends when the regions
             // are full.  Sized for the whole call when that fits log_capacity (1.2x the traces per packet measured in the last
             // call, 128 per packet before anything was measured), else log_capacity.
@@ -1238,9 +1280,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             unsigned region_capacity = (unsigned)std::min<unsigned long long>(cap / (unsigned long long)waves, 0x7fffffffull);
             if (region_capacity > 0 && region_capacity < 256) region_capacity = 256;  // (an epoch must make progress: >= 64 records per pass)
             // (waves take packets dynamically, so any wave may fill its region before the others: every launch can suspend)
-            const bool may_suspend = region_capacity > 0;
+            const bool may_suspend = region_capacity > 0 || vq;
             // a second buffer set (the estimator passes of an epoch overlap the next epoch) only when the call may need several epochs
-            const int n_sets = ctx->log_sets == 1 ? 1 : ((region_capacity > 0 && (unsigned long long)region_capacity * waves < (unsigned long long)((double)n * ctx->log_budget_per_packet)) ? 2 : 1);
+            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((region_capacity > 0 && (unsigned long long)region_capacity * waves < (unsigned long long)((double)n * ctx->log_budget_per_packet)) ? 2 : 1);
             const size_t set_records = (size_t)std::max<unsigned long long>((unsigned long long)region_capacity * waves, 1);
             for (int b = 0; b < n_sets; ++b) {
                 HIP_TRY(ctx, ctx->log_records[b].ensure(set_records * sizeof(mc::LineVisitRecord)));
@@ -1262,8 +1304,15 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             HIP_TRY(ctx, ctx->seed_chk[0].ensure((size_t)std::max<long long>(n, 1) * sizeof(mc::LaunchRec)));
             HIP_TRY(ctx, ctx->lane_save.ensure((size_t)waves * 64 * sizeof(mc::LaneSave)));
             HIP_TRY(ctx, ctx->wave_save.ensure((size_t)waves * sizeof(mc::WaveSave)));
-            HIP_TRY(ctx, ctx->suspended_dev.ensure(sizeof(unsigned)));
-            if (!ctx->suspended_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->suspended_host, sizeof(unsigned), hipHostMallocDefault));
+            HIP_TRY(ctx, ctx->suspended_dev.ensure(2 * sizeof(unsigned)));
+            if (!ctx->suspended_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->suspended_host, 4 * sizeof(unsigned), hipHostMallocDefault));
+            if (vq) {
+                HIP_TRY(ctx, ctx->vq_req.ensure((size_t)waves * 64 * sizeof(mc::VolleyRequest)));
+                HIP_TRY(ctx, ctx->vq_items.ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->vq_count.ensure(2 * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->vq_jsave.ensure((size_t)waves * 2 * (size_t)ctx->n_shells * sizeof(double)));
+                if ((size_t)waves * 64 >= (1u << 29)) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "too many lanes for the volley queue's item words");
+            }
             if (vpk) HIP_TRY(ctx, ctx->vp_scratch[0].ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(mc::VpResult)));
             HIP_TRY(ctx, ctx->wave_cold_dev.ensure(2 * sizeof(mc::WaveCold)));
             ctx->wave_cold_host.resize(2);
@@ -1288,7 +1337,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
             hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
             hot.ls_min_active = ctx->ls_min_active; hot.ls_max_steps = ctx->ls_max_steps;
-            hot.walk_min_active = ctx->walk_min_active;
+            hot.walk_min_active = ctx->walk_min_active; hot.vq_min_active = ctx->vq_min_active;
             hot.line_block = P.line_interaction_type != 0 ? P.line_block : nullptr;
             // binning + accumulation of one epoch's line-visit log (estimator_log.hpp)
             auto estimator_passes = [&](const mc::EstimatorLog &lg, int b, hipStream_t es) -> hipError_t {
@@ -1323,6 +1372,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             ctx->post_pending[0] = ctx->post_pending[1] = false;
             ctx->prop_pending = false;
             const int max_epochs = 1 << 20;
+            // volley queue: on for the bulk of a call; once a launch requests fewer v-packets than keep the tracer's lanes busy the
+            // launches are bound by their longest v-packet, not by work -- the rest of the call (the drain of the longest-lived
+            // packets) runs in ONE launch with the wave kernel's own pooled volleys
+            bool vq_on = vq;
+            const long long vq_min_items = ctx->vq_min_items >= 0 ? ctx->vq_min_items : (long long)cus * 4 * 64 * 8;
             for (int epoch = 0; n > 0 && epoch < max_epochs; ++epoch) {
                 const int b = n_sets == 2 ? (epoch & 1) : 0;
                 hipStream_t es = n_sets == 2 ? ctx->stream2 : st;  // the estimator passes of an epoch run beside the next epoch
@@ -1340,8 +1394,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 lg.n_regions = waves;
                 lg.region_capacity = region_capacity;
                 lg.region_count = ctx->log_cursor[b].as<unsigned>();
-                HIP_TRY(ctx, hipMemsetAsync(lg.region_count, 0, (size_t)waves * sizeof(unsigned), st));
-                HIP_TRY(ctx, hipMemsetAsync(ctx->suspended_dev.p, 0, sizeof(unsigned), st));
+                // (volley queue: the launches of a call go on appending to the same log regions until one of them is full)
+                if (!vq || epoch == 0) HIP_TRY(ctx, hipMemsetAsync(lg.region_count, 0, (size_t)waves * sizeof(unsigned), st));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->suspended_dev.p, 0, 2 * sizeof(unsigned), st));
+                if (vq) HIP_TRY(ctx, hipMemsetAsync(ctx->vq_count.p, 0, 2 * sizeof(unsigned), st));
                 mc::WaveCold &wc = ctx->wave_cold_host[epoch & 1];
                 wc.P = P; wc.D = F; wc.log = lg; wc.seeded_states = ctx->seeded_states.as<uint32_t>();
                 wc.chunk_first = 0; wc.chunk_count = n;
@@ -1351,22 +1407,55 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 wc.wsave = may_suspend ? ctx->wave_save.as<mc::WaveSave>() : nullptr;
                 wc.resume = epoch > 0 ? 1 : 0;
                 wc.suspended = ctx->suspended_dev.as<unsigned>();
+                wc.vq_req = vq_on ? ctx->vq_req.as<mc::VolleyRequest>() : nullptr;
+                wc.vq_items = vq_on ? ctx->vq_items.as<unsigned>() : nullptr;
+                wc.vq_count = vq ? ctx->vq_count.as<unsigned>() : nullptr;
+                wc.vq_jsave = vq ? ctx->vq_jsave.as<double>() : nullptr;
+                wc.log_continue = vq ? 1 : 0;
                 mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + (epoch & 1);
                 HIP_TRY(ctx, store_value(st, wc_dev, wc));
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[2], st));
                 hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
                 HIP_TRY(ctx, hipGetLastError());
+                if (vq_on) {  // the v-packets this launch requested (the item count is read on the device: an empty list costs a launch)
+                    const size_t geo_lds = (size_t)3 * (size_t)ctx->n_shells * sizeof(double);
+                    const int tracer_waves = cus * 4 * ctx->vq_tracer_waves_per_simd;
+                    if (full) hipLaunchKernelGGL(mc::vpacket_trace_kernel<true>, dim3(tracer_waves), dim3(64), geo_lds, st, (const mc::WaveCold *)wc_dev);
+                    else hipLaunchKernelGGL(mc::vpacket_trace_kernel<false>, dim3(tracer_waves), dim3(64), geo_lds, st, (const mc::WaveCold *)wc_dev);
+                    HIP_TRY(ctx, hipGetLastError());
+                }
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3], st));
                 if (may_suspend) {  // (read back before the estimator passes are queued: the host learns early whether another epoch follows)
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host, ctx->suspended_dev.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host, ctx->suspended_dev.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    if (vq) HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host + 2, ctx->vq_count.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4], st));
+                }
+                ctx->launches += 1;
+                if (vq) {
+                    // volley queue: the estimator passes run when a wave reports a full log region, and once at the end of the call
+                    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chunk[4]));
+                    float ms = 0.f;
+                    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_chunk[2], ctx->ev_chunk[3]));
+                    ctx->sum_prop_ms += ms;
+                    const bool last = ctx->suspended_host[0] == 0;
+                    if (last || ctx->suspended_host[1] > 0) {
+                        HIP_TRY(ctx, hipEventRecord(ctx->ev_post[0], st));
+                        HIP_TRY(ctx, estimator_passes(lg, 0, st));
+                        HIP_TRY(ctx, hipEventRecord(ctx->ev_post[1], st));
+                        HIP_TRY(ctx, hipMemsetAsync(lg.region_count, 0, (size_t)waves * sizeof(unsigned), st));
+                        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_post[1]));
+                        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_post[0], ctx->ev_post[1]));
+                        ctx->sum_post_ms += ms;
+                    }
+                    if (last) break;
+                    if (vq_on && (long long)ctx->suspended_host[2] < vq_min_items) vq_on = false;
+                    continue;
                 }
                 if (es != st) HIP_TRY(ctx, hipStreamWaitEvent(es, ctx->ev_chunk[3], 0));
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_post[2 * b], es));
                 HIP_TRY(ctx, estimator_passes(lg, b, es));
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_post[2 * b + 1], es));
                 ctx->post_pending[b] = true;
-                ctx->launches += 1;
                 ctx->prop_pending = true;
                 if (!may_suspend) break;  // (no log: the kernel adds its terms directly and never suspends; the call stays asynchronous)
                 // is anything suspended?  (the only host synchronisation of a call: once per epoch)

@@ -115,7 +115,8 @@ class Engine:
         return {"seed_ms": a.value, "propagate_ms": b.value, "launches": n.value, "estimator_ms": e.value}
 
     def last_variant(self) -> int:
-        """Propagation kernel of the last propagate(): 0 lane, 1 group, 2 wave + group sweeps, 3 wave + lane sweeps."""
+        """Propagation kernel of the last propagate(): 0 lane, 1 group, 2 wave + group sweeps, 3 wave + lane sweeps,
+        4 wave + volley queue (v-packets traced by vpacket_trace_kernel between its launches)."""
         return int(self._L.tardis_mc_last_variant(self._h))
 
     def get_results(self, output_nus=None, output_energies=None, track_last_interaction=True,

@@ -98,11 +98,12 @@ def test_hip_matches_oracle_and_reference_on_golden_cases(engine, oracle, name):
     _check_golden_case(engine, oracle, name)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("name", [n for n in _golden.CASES if "_nv2" in n or "_nv3" in n])
 def test_every_kernel_variant_on_vpacket_golden_cases(engine, oracle, name, variant):
-    """The automatic choice sends v-packet problems to the group kernel; the wave-owner kernel's lane-per-packet volleys and
-    the lane kernel must reproduce the same goldens (incl. the consolidated v-packet log)."""
+    """Whatever the automatic choice for a v-packet problem is, the group kernel, the wave-owner kernel's pooled volleys, its
+    volley queue (variant 4: v-packets traced by a kernel of their own between its launches) and the lane kernel must all
+    reproduce the same goldens (incl. the consolidated v-packet log)."""
     engine.set_option("variant", variant)
     try:
         _check_golden_case(engine, oracle, name)
