@@ -432,17 +432,22 @@ __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &r
                 e = max(P.bucket_first[kk], start + 1);
                 if (e > L - 1) e = L - 1;
                 // (lines after `start` cannot raise: the list is sorted, their nu_diff is larger than that of `start`)
-                auto stops_at = [&](int k) -> bool {
+                auto stops_at_nu = [&](int k, double nl) -> bool {
                     double d;
-                    (void)distance_line<FULL>(nu, r, mu, comov_nu, k == L - 1, P.nu_line[(unsigned)k], t, d);
+                    (void)distance_line<FULL>(nu, r, mu, comov_nu, k == L - 1, nl, t, d);
                     return d_boundary <= d;
                 };
+                auto stops_at = [&](int k) -> bool { return stops_at_nu(k, P.nu_line[(unsigned)k]); };
                 // a window of four lines around the bucket guess in ONE round trip (the walk below -- one dependent load per
-                // line -- only if the guess was further off)
+                // line -- only if the guess was further off); two 16-byte loads: the list ends in slack, and an index clamped
+                // to the last line does not look at its frequency
                 const int w0 = max(e - 1, start + 1);
+                typedef double nu2 __attribute__((ext_vector_type(2), aligned(8)));
+                const nu2 wa = *reinterpret_cast<const nu2 *>(P.nu_line + (unsigned)w0), wb = *reinterpret_cast<const nu2 *>(P.nu_line + (unsigned)w0 + 2);
+                const double wn[4] = {wa.x, wa.y, wb.x, wb.y};
                 bool sw[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sw[i] = stops_at(min(w0 + i, L - 1));
+                for (int i = 0; i < 4; ++i) sw[i] = stops_at_nu(min(w0 + i, L - 1), wn[i]);
                 bool resolved = false, stops = false;
                 if (sw[0]) {
                     if (w0 == start + 1) { e = w0; stops = true; resolved = true; }
@@ -469,22 +474,29 @@ __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &r
             // serial-order sum of tau over [start, e): the loads are independent of the adds, so VP_SUM_BATCH of them are in flight
             // per round trip (a shell crossing of the 5e5-line list passes ~40 lines: with four at a time the sum alone was a chain
             // of ten dependent round trips)
+            // (two optical depths per load instruction: the address unit's time goes by lanes x instructions, and these per-lane
+            // runs of a row are what keeps it 65 % busy on the 100-shell shape; rows are 8-byte aligned, the table ends in slack)
+            typedef double tau2 __attribute__((ext_vector_type(2), aligned(8)));
             const double *__restrict__ trow = P.tau_t + row;
             int k = start;
             const int e_sum = min(e, L);
             for (; k + VP_SUM_BATCH <= e_sum; k += VP_SUM_BATCH) {
-                double tb[VP_SUM_BATCH];
+                tau2 tb[VP_SUM_BATCH / 2];
 #pragma unroll
-                for (int q = 0; q < VP_SUM_BATCH; ++q) tb[q] = trow[(unsigned)(k + q)];
+                for (int q = 0; q < VP_SUM_BATCH / 2; ++q) tb[q] = *reinterpret_cast<const tau2 *>(trow + (unsigned)(k + 2 * q));
 #pragma unroll
-                for (int q = 0; q < VP_SUM_BATCH; ++q) tau_shell += tb[q];
+                for (int q = 0; q < VP_SUM_BATCH / 2; ++q) { tau_shell += tb[q].x; tau_shell += tb[q].y; }
             }
             if (k < e_sum) {  // the rest (< VP_SUM_BATCH lines), again in one round trip; +0.0 where there is no line
-                double tb[VP_SUM_BATCH];
+                tau2 tb[VP_SUM_BATCH / 2];
 #pragma unroll
-                for (int q = 0; q < VP_SUM_BATCH; ++q) tb[q] = (k + q < e_sum) ? trow[(unsigned)(k + q)] : 0.0;
+                for (int q = 0; q < VP_SUM_BATCH / 2; ++q) {
+                    const tau2 z = {0.0, 0.0};
+                    tb[q] = (k + 2 * q < e_sum) ? *reinterpret_cast<const tau2 *>(trow + (unsigned)(k + 2 * q)) : z;
+                    if (!(k + 2 * q + 1 < e_sum)) tb[q].y = 0.0;
+                }
 #pragma unroll
-                for (int q = 0; q < VP_SUM_BATCH; ++q) tau_shell += tb[q];
+                for (int q = 0; q < VP_SUM_BATCH / 2; ++q) { tau_shell += tb[q].x; tau_shell += tb[q].y; }
             }
             vvisits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
             next_line = e;

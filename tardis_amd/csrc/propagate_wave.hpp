@@ -417,11 +417,16 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
     // requested first: the line at `start` and -- speculatively -- the first eight optical depths of the sum.
     const int start_c = min(start, L - 1);
     const double *__restrict__ trow = P.tau_t + row + (unsigned)start_c;
-    const int last_ok = L - 1 - start_c;  // highest in-bounds offset
     const double nl_start = P.nu_line[(unsigned)start_c];
+    // (two optical depths per load instruction; past the end of the table there is slack, and what lies beyond the lines of the
+    // sum is replaced by +0.0 before it is used)
+    typedef double tau2 __attribute__((ext_vector_type(2), aligned(8)));
     double tv[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tv[k] = trow[(unsigned)min(k, last_ok)];
+    for (int k = 0; k < 8; k += 2) {
+        const tau2 w = *reinterpret_cast<const tau2 *>(trow + k);
+        tv[k] = w.x; tv[k + 1] = w.y;
+    }
     // trace_vpacket_within_shell (:82-175)
     double d_boundary;
     int delta;
@@ -464,12 +469,13 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
             e = max(bucket_e, start + 1);
             if (e > L - 1) e = L - 1;
             const int w0 = max(e - 1, start + 1);
+            // (two 16-byte loads: the list ends in slack, and an index clamped to the last line does not look at its frequency)
+            typedef double nu2 __attribute__((ext_vector_type(2), aligned(8)));
+            const nu2 wa = *reinterpret_cast<const nu2 *>(P.nu_line + (unsigned)w0), wb = *reinterpret_cast<const nu2 *>(P.nu_line + (unsigned)w0 + 2);
+            const double wn[4] = {wa.x, wa.y, wb.x, wb.y};
             bool sw[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = min(w0 + i, L - 1);
-                sw[i] = d_boundary <= d_line_of(k, P.nu_line[(unsigned)k]);
-            }
+            for (int i = 0; i < 4; ++i) sw[i] = d_boundary <= d_line_of(min(w0 + i, L - 1), wn[i]);
             bool resolved = false, stops = false;
             if (sw[0]) {
                 if (w0 == start + 1) { e = w0; stops = true; resolved = true; }
@@ -503,9 +509,11 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
     for (int k = 0; k < 8; ++k) tau_shell += (k < n_sum) ? tv[k] : 0.0;
     for (int base = 8; __ballot(base < n_sum); base += 8) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 8; k += 2) {
             const int o = base + k;
-            tv[k] = (o < n_sum) ? trow[(unsigned)min(o, last_ok)] : 0.0;
+            const tau2 z = {0.0, 0.0};
+            const tau2 w = (o < n_sum) ? *reinterpret_cast<const tau2 *>(trow + o) : z;
+            tv[k] = w.x; tv[k + 1] = (o + 1 < n_sum) ? w.y : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) tau_shell += tv[k];

@@ -20,6 +20,10 @@ if os.environ.get("EXP_SHAPE") == "config2v":
     shape = dict(n_shells=20, n_lines=30_000, line_interaction_type="downbranch", n_vpackets=10)
 if os.environ.get("EXP_SHAPE") == "config5":
     shape = dict(n_shells=100, n_lines=500_000, line_interaction_type="macroatom", n_vpackets=10)
+if os.environ.get("EXP_LOG_TAU"):  # thinner / thicker lines than the default synthetic ejecta (log10 of the mean Sobolev depth)
+    shape["log_tau_mean"] = float(os.environ["EXP_LOG_TAU"])
+if os.environ.get("EXP_NE0"):
+    shape["electron_density_0"] = float(os.environ["EXP_NE0"])
 prob = synthetic.make_problem(seed=1, n_packets=1, **shape)
 eng = Engine(0)
 eng.set_geometry(prob.geometry, prob.time_explosion)
@@ -46,6 +50,7 @@ for e in exps:
     sig = (c["line_visits"], c["events"], c["macro_transitions"], c["rng_draws"])
     if ref is None:
         ref = sig
+    vp = f" vp/pkt {c['vpackets'] / P:7.1f} vpvis/vp {c['vpacket_line_visits'] / max(c['vpackets'], 1):7.1f}" if c.get("vpackets") else ""
     print(f"{e:60s} {best:9.2f} ms  {P / best / 1e3:7.2f} Mpkt/s  propagate {kt['propagate_ms']:8.2f} ms x{kt['launches']}  "
-          f"est {kt['estimator_ms']:7.2f} ms  counters {'same' if sig == ref else 'DIFFER ' + str(sig)}  c7={c['reserved']}", flush=True)
+          f"est {kt['estimator_ms']:7.2f} ms  counters {'same' if sig == ref else 'DIFFER ' + str(sig)}  c7={c['reserved']}{vp}", flush=True)
 eng.close()
