@@ -150,7 +150,11 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
 
 /* Tunables.  name: "track_last_interaction" (0/1, default 1), "vpacket_log_capacity" (entries),
  * "variant" (kernel variant: -1 automatic, 0 lane-per-packet, 1 group-per-packet, 2 wave-owner with group sweeps, 3 wave-owner
- * with lane sweeps), "lane_sweep_min_active" / "lane_sweep_max_steps" (when variant 3 leaves its sweep phase),
+ * with lane sweeps, 4 wave-owner with the volley queue: v-packets traced by a kernel of their own between its launches --
+ * never the automatic choice; falls back to 2/3 without v-packets and to 1 with a survival probability > 0),
+ * "vq_min_items" (variant 4: switch the queue off for the rest of a call once a launch requests fewer v-packets; -1 automatic,
+ * 0 never), "vq_min_active", "vq_oversubscribe", "vq_tracer_waves_per_simd" (variant 4 launch shape),
+ * "lane_sweep_min_active" / "lane_sweep_max_steps" (when variant 3 leaves its sweep phase),
  * "walk_min_active" (macroatom walks are carried over to the next pass once this few lanes still walk; -1 never),
  * "log_capacity" (line-visit records per epoch and buffer set of the wave-owner kernel; a call that logs more runs as several
  * launches over one packet supply), "log_sets" (1: the estimator passes of an epoch run before the next
@@ -184,7 +188,8 @@ int tardis_mc_last_estimator_ms(TardisMcContext *ctx, double *out_ms);
  * of resonances crossed by all rays) */
 int tardis_mc_last_counters(TardisMcContext *ctx, int64_t out_counters[TARDIS_MC_N_COUNTERS]);
 /* Which propagation kernel the last tardis_mc_propagate ran (the "variant" option, or the automatic choice): 0 lane-per-packet,
- * 1 group-per-packet, 2 wave-owner with group sweeps, 3 wave-owner with lane sweeps; -1 before the first call. */
+ * 1 group-per-packet, 2 wave-owner with group sweeps, 3 wave-owner with lane sweeps, 4 wave-owner with the volley queue;
+ * -1 before the first call. */
 int tardis_mc_last_variant(TardisMcContext *ctx);
 /* Per-packet results of the resident packets + estimators (re-laid to [L,S]) to caller memory. */
 int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *result);
