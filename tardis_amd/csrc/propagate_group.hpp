@@ -407,6 +407,10 @@ __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &r
         // resonance distance is >= the boundary distance and adds up their tau in that order.  The stopping predicate is
         // monotone along the (descending) line list, so the stopping index is located through the frequency-bucket
         // index and then pinned with the reference's own predicate; the tau sum keeps the reference's order.
+        // (a crossing is a chain of dependent round trips: the line at `start` is requested together with the geometry, and the
+        // frequency bucket of the boundary as soon as the boundary distance is there -- not behind the test of the line at `start`)
+        const int start = next_line;
+        const double nl_start = P.nu_line[(unsigned)min(start, L - 1)];
         double d_boundary;
         int delta;
         distance_boundary(r, mu, P.r_inner[shell], P.r_outer[shell], d_boundary, delta);
@@ -418,18 +422,18 @@ __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &r
         if (FULL) chi_cont *= dop;
         double tau_shell = chi_cont * d_boundary;
         const unsigned row = (unsigned)shell * (unsigned)L;
-        const int start = next_line;
+        // approximate stopping frequency: nu_line ~ comov_nu - d_boundary nu / (c t)
+        const double nu_thr = comov_nu - d_boundary * P.rcp_tc * nu;
+        long long kk = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
+        kk = kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
+        const int bucket_e = P.bucket_first[kk];
         if (start < L) {
             double d_line;
             // the reference evaluates line `start` first and raises there if it lies blueward of the packet
-            if (!distance_line<FULL>(nu, r, mu, comov_nu, start == L - 1, P.nu_line[(unsigned)start], t, d_line)) return ERR_MONTECARLO;
+            if (!distance_line<FULL>(nu, r, mu, comov_nu, start == L - 1, nl_start, t, d_line)) return ERR_MONTECARLO;
             int e = start;
             if (!(d_boundary <= d_line)) {
-                // approximate stopping frequency: nu_line ~ comov_nu - d_boundary nu / (c t)
-                const double nu_thr = comov_nu - d_boundary * P.rcp_tc * nu;
-                long long kk = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
-                kk = kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
-                e = max(P.bucket_first[kk], start + 1);
+                e = max(bucket_e, start + 1);
                 if (e > L - 1) e = L - 1;
                 // (lines after `start` cannot raise: the list is sorted, their nu_diff is larger than that of `start`)
                 auto stops_at_nu = [&](int k, double nl) -> bool {
