@@ -396,7 +396,7 @@ constexpr int VP_SUM_BATCH = 16;  // optical depths a lane requests per round tr
 
 template <bool FULL, int G>
 __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &rng, VpDraws &dr, double r, double mu, double nu,
-                                        double &energy, int shell, int next_line, double &tau_out, unsigned &vvisits)
+                                        double &energy, int shell, int next_line, double &tau_out, unsigned &vvisits, const double *geo)
 {
     const int L = P.n_lines;
     const double t = P.t_exp;
@@ -413,8 +413,8 @@ __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &r
         const double nl_start = P.nu_line[(unsigned)min(start, L - 1)];
         double d_boundary;
         int delta;
-        distance_boundary(r, mu, P.r_inner[shell], P.r_outer[shell], d_boundary, delta);
-        const double chi_e = P.n_e[shell] * P.sigma_thomson;
+        distance_boundary(r, mu, geo[shell], geo[P.n_shells + shell], d_boundary, delta);
+        const double chi_e = geo[2 * P.n_shells + shell] * P.sigma_thomson;
         const double velocity = r / t;
         const double dop = doppler_factor<FULL>(velocity, mu);
         const double comov_nu = nu * dop;
@@ -531,7 +531,8 @@ __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &r
 
 template <bool FULL, int G>
 __device__ __forceinline__ int volley_group(const GroupArgs &P, const Packet &p, GroupRng<G> &rng, const int j, long long packet_index,
-                                            int &vseq, unsigned &pred_bits, unsigned &vvisits, unsigned &vcount, unsigned long long &vtraced)
+                                            int &vseq, unsigned &pred_bits, unsigned &vvisits, unsigned &vcount, unsigned long long &vtraced,
+                                            const double *geo)
 {   // trace_vpacket_volley (:248-386)
     if (p.nu < P.spawn_start || p.nu > P.spawn_end) return 0;
     const int n_v = (int)P.n_vpackets;
@@ -599,7 +600,7 @@ __device__ __forceinline__ int volley_group(const GroupArgs &P, const Packet &p,
             v_nu = p.nu * ratio;
             v_energy = p.energy * weight * ratio;
             double tau_v;
-            err = vp_trace<FULL, G>(P, rng, dr, p.r, v_mu, v_nu, v_energy, p.shell, p.next_line_id, tau_v, my_visits);
+            err = vp_trace<FULL, G>(P, rng, dr, p.r, v_mu, v_nu, v_energy, p.shell, p.next_line_id, tau_v, my_visits, geo);
             if (!err) v_energy *= mcm::exp(-tau_v);
             if (dr.overflow) err = ERR_UNSUPPORTED;
         }
@@ -648,7 +649,7 @@ __device__ __forceinline__ int volley_group(const GroupArgs &P, const Packet &p,
 template <int G, int BLOCK>
 __host__ __device__ constexpr size_t group_kernel_lds_bytes(int n_shells)
 {
-    return (size_t)(BLOCK / G) * sizeof(LdsTracker) + 2 * (size_t)n_shells * sizeof(double);  // J, nu_bar
+    return (size_t)(BLOCK / G) * sizeof(LdsTracker) + 5 * (size_t)n_shells * sizeof(double);  // J, nu_bar; r_inner, r_outer, n_e for the v-packet traces
 }
 
 template <bool FULL, bool TRACK, int G, int BLOCK, int OCC, bool VPK>
@@ -661,6 +662,11 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
     double *lds_J = reinterpret_cast<double *>(lds_raw + NGROUPS * sizeof(LdsTracker));
     double *lds_nubar = lds_J + P.n_shells;
     for (int s = threadIdx.x; s < 2 * P.n_shells; s += BLOCK) lds_J[s] = 0.0;
+    double *lds_geo = lds_nubar + P.n_shells;  // r_inner | r_outer | n_e: the first link of every shell crossing's chain of look-ups
+    if (VPK)
+        for (int s = threadIdx.x; s < P.n_shells; s += BLOCK) {
+            lds_geo[s] = P.r_inner[s]; lds_geo[P.n_shells + s] = P.r_outer[s]; lds_geo[2 * P.n_shells + s] = P.n_e[s];
+        }
     __syncthreads();
 
     const int j = threadIdx.x & (G - 1);
@@ -787,7 +793,7 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
             const unsigned long long live_mask = __ballot(live), want_mask = __ballot(live && want_volley);
             if (want_mask != 0ull && want_mask == live_mask) {
                 if (live && want_volley) {
-                    const int verr = volley_group<FULL, G>(P, p, rng, j, chunk_first + pkt, vseq, pred_bits, vvisits, vcount, vtraced);
+                    const int verr = volley_group<FULL, G>(P, p, rng, j, chunk_first + pkt, vseq, pred_bits, vvisits, vcount, vtraced, lds_geo);
                     want_volley = false;
                     if (verr) {
                         if (j == 0) {
