@@ -490,3 +490,28 @@ def test_log_bounded_epochs_match_the_oracle(oracle):
         for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
             assert got.counters[k] == ref.counters[k], k
     eng.close()
+
+
+@pytest.mark.gpu
+def test_negative_optical_depths(oracle):
+    """A table with negative Sobolev depths (stimulated emission can produce them): the running optical depth of a trace then
+    decreases along the list, which the no-stop bounds of the lane sweeps do not rely on -- the result is the oracle's."""
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=23, n_packets=20_000, n_shells=10, n_lines=6_000, line_interaction_type="macroatom")
+    tau = np.array(prob.opacity_state.tau_sobolev, copy=True)
+    tau[::7, ::3] *= -0.25
+    prob.opacity_state.tau_sobolev = tau
+    ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
+    eng = Engine(0)
+    eng.set_option("variant", 3)
+    eng.set_geometry(prob.geometry, prob.time_explosion)
+    eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+    eng.set_packets(prob.packet_collection)
+    eng.reset_estimators(); eng.propagate(); eng.synchronize()
+    got = eng.get_results(track_last_interaction=True)
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+    for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
+        assert got.counters[k] == ref.counters[k], k
+    eng.close()
