@@ -59,8 +59,23 @@ def algorithmic_bytes(c: dict, part: str = "step") -> float:
     per_visit = {"step": 48.0, "propagate": 16.0, "estimators": 32.0}[part]
     if part == "estimators":
         return per_visit * c["line_visits"]
-    return (per_visit * c["line_visits"] + 56.0 * c["events"] + 8.0 * c["macro_transitions"] + 16.0 * c["vpacket_line_visits"]
+    return (per_visit * c["line_visits"] + 56.0 * c["events"] + walk_bytes(c) + 16.0 * c["vpacket_line_visits"]
             + 56.0 * c["packets"])
+
+
+def walk_bytes(c: dict) -> float:
+    """Macro-atom term of the byte model.  SURVEY §8(d) prices the reference's serial walk: 8 B per transition examined (M).
+    With heavy-tailed blocks M is tens of thousands per packet and a serial walk is no lower bound any more: a jump is a
+    search in the block's running sums, which needs one 64-byte window of them and the 16-byte record of the selected
+    transition.  So the term is min(8 M, 80 J) with J = rng_draws - 2 events, a LOWER bound of the number of jumps (every
+    event draws tau_event, at most every event ends in an interaction that draws a direction, every jump draws once; only
+    without v-packets, whose draws are not jumps).  On the 4-8-line levels of rounds 1-2 both sides agree to 0.3 % (9 rows
+    examined per jump)."""
+    serial = 8.0 * c["macro_transitions"]
+    if c["vpackets"] > 0 or c["macro_transitions"] == 0:
+        return serial
+    jumps_lb = max(c["rng_draws"] - 2 * c["events"], 0)
+    return min(serial, 80.0 * jumps_lb)
 
 
 def main():
@@ -76,6 +91,9 @@ def main():
     ap.add_argument("--shells", type=int, default=None)
     ap.add_argument("--mode", type=str, default=None)
     ap.add_argument("--vpackets", type=int, default=None)
+    ap.add_argument("--level-sizes", type=str, default="uniform", choices=["uniform", "heavy"],
+                    help="macro-atom block sizes of the synthetic opacity state: 'uniform' = 4-8 lines per level (rounds 1-2), "
+                         "'heavy' = heavy-tailed (Pareto, up to 6000 lines = 18000 rows per block, probabilities over many decades)")
     ap.add_argument("--no-tracking", action="store_true", help="skip the last-interaction tracker outputs")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="packets in the CPU-baseline sample (0: skip; default sized for ~15 s of CPU work)")
@@ -110,7 +128,7 @@ def main():
         kw["n_packets"] //= 8  # those configs quote the 8-GPU total
     P = int(kw.pop("n_packets"))
     # opacities, geometry, configuration on the host (same on every rank); the packets never exist on the host
-    prob = synthetic.make_problem(seed=1, n_packets=1, **kw)
+    prob = synthetic.make_problem(seed=1, n_packets=1, level_sizes=args.level_sizes, **kw)
 
     eng = Engine(pg.local_rank if args.all_on_device is None else args.all_on_device)
     if args.variant is not None:
@@ -177,7 +195,8 @@ def main():
             "workload": f"BASELINE configs[{args.config - 1}]: {P} packets/GPU/step, "
                         f"{kw['n_shells']} shells, {kw['n_lines']} lines, {mode}, "
                         f"{kw.get('n_vpackets', 0)} v-packets, last-interaction tracking "
-                        f"{'off' if args.no_tracking else 'on'}; synthetic opacities (SURVEY 8d), packets from the "
+                        f"{'off' if args.no_tracking else 'on'}; synthetic opacities (SURVEY 8d"
+                        f"{', heavy-tailed macro-atom blocks' if args.level_sizes == 'heavy' else ''}), packets from the "
                         f"device black-body source (T_inner = {T_INNER:g} K)",
             "packets_per_gpu": P, "n_shells": kw["n_shells"], "n_lines": kw["n_lines"],
             "line_interaction_type": mode, "n_vpackets": kw.get("n_vpackets", 0),
@@ -189,9 +208,9 @@ def main():
         # dominant kernel = the propagation kernel; its launches of one step are timed with HIP events on the streams they run on
         launches = max(ktimes["launches"], 1)
         variant = eng.last_variant()  # (the engine's automatic choice unless --variant was given)
-        wave = variant in (2, 3)
+        wave = variant in (2, 3, 4)
         dominant = {0: "propagate_lane_kernel", 1: "propagate_group_kernel", 2: "propagate_wave_kernel (group sweeps)",
-                    3: "propagate_wave_kernel (lane sweeps)"}[variant]
+                    3: "propagate_wave_kernel (lane sweeps)", 4: "propagate_wave_kernel (volley queue)"}.get(variant, f"variant {variant}")
         kernel_ms = ktimes["propagate_ms"] / launches
         # the dominant kernel's own algorithmic bytes (see algorithmic_bytes) over its HIP-event duration
         bytes_per_launch = algorithmic_bytes(counters, "propagate" if wave else "step") / launches
@@ -203,8 +222,9 @@ def main():
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel": f"{dominant} (dominant kernel of a step)", "kernel_ms": kernel_ms,
                            "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "note": "kernel_ms = mean HIP-event duration of the step's propagation launches; chunks alternate between two "
-                                   "streams and overlap, so launches x kernel_ms can exceed the step's device time",
+                           "note": "kernel_ms = mean HIP-event duration of the step's propagation launches (the epochs of one "
+                                   "tardis_mc_propagate call, back to back on the engine's stream; the estimator passes of an epoch run "
+                                   "beside the next one on a second stream)",
                            "step": {"algorithmic_bytes": step_bytes, "device_ms": last_ms, "achieved": step_achieved,
                                     "frac": step_achieved / HBM_PEAK_GBS, "seed_kernel_ms": ktimes["seed_ms"],
                                     "estimator_passes_ms": ktimes.get("estimator_ms", 0.0),
@@ -227,7 +247,8 @@ def measured_traffic(args, P: int, launches: int):
     """HBM bytes per launch of the propagation kernel from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes collected on this
     workload (tools/gpu_profile.sh -> profiles/pmc_traffic_config<N>.json, corrected as MI355X_MICROARCH.md prescribes);
     None when the file was collected on another workload."""
-    custom = any(v is not None for v in (args.lines, args.shells, args.mode, args.vpackets, args.variant)) or args.no_tracking or args.option
+    custom = (any(v is not None for v in (args.lines, args.shells, args.mode, args.vpackets, args.variant)) or args.no_tracking or args.option
+              or args.level_sizes != "uniform")
     path = os.path.join(ROOT, "profiles", f"pmc_traffic_config{args.config}.json")
     if custom or not os.path.exists(path):
         return None

@@ -161,7 +161,9 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
  * epoch instead of beside it), "chunk_packets" (packets per launch of the group kernel), "waves_per_simd", "group_size",
  * "blocks_per_cu", "estimator_copies" (1..8 private j_blue/Edotlu copies),
  * "debug_flags" (profiling experiments / cross-checks only: 1 skips the j_blue/Edotlu updates, 2 the J/nu_bar updates, 128
- * walks the macro atom by a per-lane search in the fp64 running sums, 8192 by the cooperative group scan). */
+ * walks the macro atom by a per-lane search in the fp64 running sums, 8192 by the cooperative group scan; tests: 16384 counts
+ * the jumps out of blocks longer than one window of the compact walk tables into counters[7], 32768 the jumps decided by the
+ * fp64 running sums because 16-bit entries tie). */
 int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value);
 
 /* ---- staged API: inputs resident in HBM, kernels timed separately -------------------------------- */
@@ -172,8 +174,16 @@ int tardis_mc_set_config(TardisMcContext *ctx, const TardisMcConfig *config);
 int tardis_mc_set_packets(TardisMcContext *ctx, const TardisMcPackets *packets);
 /* Zero J, nu_bar, j_blue, Edotlu, v-hist and the counters (start of an iteration). */
 int tardis_mc_reset_estimators(TardisMcContext *ctx);
-/* Launch the propagation kernels for the resident packets on the context stream (asynchronous).
- * Estimators ACCUMULATE across calls until tardis_mc_reset_estimators (packet chunks of one iteration). */
+/* Launch the propagation kernels for the resident packets on the context stream.
+ * Estimators ACCUMULATE across calls until tardis_mc_reset_estimators (packet chunks of one iteration).
+ * Blocking behaviour: the lane and group kernels (variants 0, 1) are queued and the call returns at once.  The wave-owner
+ * kernel (variants 2-4, the automatic choice for sorted line lists) runs a call as a sequence of launches ("epochs") over one
+ * packet supply; after every launch the HOST waits for one word (did any wave suspend on a full line-visit log region?) to
+ * decide whether another launch follows, so the call returns when the LAST propagation launch has been queued and all earlier
+ * ones have finished -- for a one-epoch call that is after its only launch.  The estimator passes of the last epoch, the
+ * tracker unpacking and the result copies are still asynchronous: call tardis_mc_synchronize before reading results.  One host
+ * thread driving several contexts therefore serialises their propagations; use one thread (or process) per context.
+ * Returns TARDIS_MC_ERR_STATE if the launch bound of a call is exhausted with waves still suspended (results incomplete). */
 int tardis_mc_propagate(TardisMcContext *ctx);
 int tardis_mc_synchronize(TardisMcContext *ctx);
 /* Device time of the kernels launched by the last tardis_mc_propagate (HIP events on the ctx stream). */

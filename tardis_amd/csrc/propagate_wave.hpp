@@ -589,6 +589,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     unsigned log_used = 0;  // wave-uniform: records this wave has appended to its log region
     unsigned long long visits = 0;
     unsigned dbg_rounds = 0;  // wave-uniform profiling counter: sweep rounds (reported through counters[7])
+    unsigned dbg_walk = 0;    // wave-uniform test counter (debug_flags 16384: jumps out of blocks longer than one window; 32768: jumps decided by the fp64 sums)
     // lane sweep (LS): the trace this lane is sweeping (it may span several passes of the event loop).  What only the exact
     // evaluation of a line needs is parked in LDS: chi in sh.d_cont0, the boundary distance in sh.d_boundary (where the
     // result goes, too); the packet's nu and Doppler factor are the owner's p.nu and dop.
@@ -890,6 +891,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     x = (unsigned)(event * 65536.0);  // floor: event is in [0, 1)
                     q_hi = (mb1 + 7) >> 3;
                 }
+                if (H.debug_flags & 16384) dbg_walk += (unsigned)__popcll(__ballot(in_macro && mb1 > 8 * WALK_WINDOW_QUADS));  // tests: jumps out of long blocks
                 // blocks of more than 32 transitions: first quad whose last entry is not below x (entries are monotone)
                 while (__ballot(in_macro && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1)) {
                     if (in_macro && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1) {
@@ -899,6 +901,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     }
                 }
                 int sel = -1;  // position of the selected transition in its block; -1: the block ran out
+                bool exact = false;
                 if (in_macro) {
                     const int n_quads = (mb1 + 7) >> 3;
                     const int nq = min(WALK_WINDOW_QUADS, n_quads - q_lo);
@@ -917,6 +920,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     const int n_less = (int)((less & 0xffffu) + (less >> 16)), n_gt = (int)((gt & 0xffffu) + (gt >> 16));
                     int k = 8 * q_lo + n_less;  // every entry before it is surely <= the number drawn
                     if (8 * nq - n_gt - n_less > 0) {
+                        exact = true;
                         // entries equal to x (2^-16 of the draws per entry; the 0xffff padding when x = 65535): the reference's
                         // own comparison on the fp64 running sums, in order
                         const double *__restrict__ cum = P.cum_t + (size_t)p.shell * (size_t)P.n_trans;
@@ -930,6 +934,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     if (k < mb1) sel = k;
                     macro += (unsigned)(sel >= 0 ? sel + 1 : mb1);
                 }
+                if (H.debug_flags & 32768) dbg_walk += (unsigned)__popcll(__ballot(exact));  // tests: jumps decided by the fp64 sums
                 if (in_macro) {
                     if (sel < 0) { err = ERR_MACRO_ATOM; in_macro = false; }
                     else {
@@ -1634,6 +1639,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             }
         }
         if (H.debug_flags & 16) atomicAdd(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
+        if (H.debug_flags & (16384 | 32768)) atomicAdd(&C->counters[7], (unsigned long long)dbg_walk);  // tests only
         if (H.debug_flags & 32) atomicAdd(&C->counters[7], (unsigned long long)dbg_passes);
 #ifdef TMC_SECTION_TIMERS
         if (H.debug_flags & 64) {

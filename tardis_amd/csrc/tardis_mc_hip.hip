@@ -1169,6 +1169,12 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 
     if (!cooperative) {
         // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment
+        // (the context is cached: the timing queries must not report the epochs of an earlier wave-kernel call)
+        ctx->wave_epoch_mode = false;
+        ctx->post_pending[0] = ctx->post_pending[1] = false;
+        ctx->prop_pending = false;
+        ctx->sum_seed_ms = ctx->sum_prop_ms = ctx->sum_post_ms = 0.0;
+        ctx->launches = 0;
         long long want_blocks = (ctx->n_packets + 255) / 256;
         int blocks = (int)std::max<long long>(1, std::min<long long>(want_blocks, (long long)cus * ctx->blocks_per_cu));
         HIP_TRY(ctx, ctx->rng_state.ensure((size_t)blocks * 256 * mc::MT_N * sizeof(uint32_t)));
@@ -1377,6 +1383,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             // packets) runs in ONE launch with the wave kernel's own pooled volleys
             bool vq_on = vq;
             const long long vq_min_items = ctx->vq_min_items >= 0 ? ctx->vq_min_items : (long long)cus * 4 * 64 * 8;
+            bool call_complete = n <= 0;
             for (int epoch = 0; n > 0 && epoch < max_epochs; ++epoch) {
                 const int b = n_sets == 2 ? (epoch & 1) : 0;
                 hipStream_t es = n_sets == 2 ? ctx->stream2 : st;  // the estimator passes of an epoch run beside the next epoch
@@ -1447,7 +1454,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_post[0], ctx->ev_post[1]));
                         ctx->sum_post_ms += ms;
                     }
-                    if (last) break;
+                    if (last) { call_complete = true; break; }
                     if (vq_on && (long long)ctx->suspended_host[2] < vq_min_items) vq_on = false;
                     continue;
                 }
@@ -1457,15 +1464,17 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_post[2 * b + 1], es));
                 ctx->post_pending[b] = true;
                 ctx->prop_pending = true;
-                if (!may_suspend) break;  // (no log: the kernel adds its terms directly and never suspends; the call stays asynchronous)
+                if (!may_suspend) { call_complete = true; break; }  // (no log: the kernel adds its terms directly and never suspends; the call stays asynchronous)
                 // is anything suspended?  (the only host synchronisation of a call: once per epoch)
                 HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chunk[4]));
                 float ms = 0.f;
                 HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_chunk[2], ctx->ev_chunk[3]));
                 ctx->sum_prop_ms += ms;
                 ctx->prop_pending = false;
-                if (*ctx->suspended_host == 0) break;
+                if (*ctx->suspended_host == 0) { call_complete = true; break; }
             }
+            if (!call_complete)  // (packets would be left suspended in lane_save, outputs and estimators silently incomplete)
+                return fail(ctx, TARDIS_MC_ERR_STATE, "propagate: %d launches did not finish the call (waves still suspended)", max_epochs);
             if (n_sets == 2 && (ctx->post_pending[0] || ctx->post_pending[1])) {
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -1744,14 +1753,17 @@ int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const Ta
     if ((rc = tardis_mc_set_geometry(ctx, geometry))) return rc;
     if ((rc = tardis_mc_set_opacity(ctx, opacity))) return rc;
     if ((rc = tardis_mc_set_config(ctx, config))) return rc;
+    // the caller's log capacity is for this call only, whichever way the call ends (the context is cached per process)
+    struct VlogScope {
+        TardisMcContext *c; bool was_user; long long was;
+        ~VlogScope() { c->vlog_capacity_user = was_user; if (was_user) c->vlog_capacity = was; }
+    } scope{ctx, ctx->vlog_capacity_user, ctx->vlog_capacity};
     if (result && result->vpacket_log_capacity > 0) { ctx->vlog_capacity = result->vpacket_log_capacity; ctx->vlog_capacity_user = true; }
     if ((rc = tardis_mc_set_packets(ctx, packets))) return rc;
     if ((rc = tardis_mc_reset_estimators(ctx))) return rc;
     if ((rc = tardis_mc_propagate(ctx))) return rc;
     if ((rc = tardis_mc_synchronize(ctx))) return rc;
-    rc = tardis_mc_get_results(ctx, result);
-    ctx->vlog_capacity_user = false;  // (the caller's capacity was for this call only)
-    return rc;
+    return tardis_mc_get_results(ctx, result);
 }
 
 int tardis_mc_packet_spectrum(TardisMcContext *ctx, double time_of_simulation, double luminosity_nu_start,

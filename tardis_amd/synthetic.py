@@ -65,7 +65,8 @@ def make_geometry(n_shells: int = 20, v_inner: float = 1.1e9, v_outer: float = 2
 def make_opacity_state(seed: int, geometry: st.HomologousRadial1DGeometry, n_lines: int,
                        line_interaction_type: str, log_tau_mean: float = -4.0, log_tau_sigma: float = 2.0,
                        electron_density_0: float = 1e9,
-                       shell_independent_probabilities: bool = False) -> st.OpacityState:
+                       shell_independent_probabilities: bool = False,
+                       level_sizes: str = "uniform") -> st.OpacityState:
     rng = np.random.default_rng(seed)
     n_shells = len(geometry.r_inner)
     # lines: log-uniform in wavelength on [500 A, 20000 A]; frequency sorted descending
@@ -85,14 +86,34 @@ def make_opacity_state(seed: int, geometry: st.HomologousRadial1DGeometry, n_lin
         op.tau_factors = (tau0, rho)
         return op
 
-    # macro-atom levels: every level owns 4-8 emission lines, lines assigned at random so that a
+    # macro-atom levels: every level owns 4-8 emission lines ("uniform"), lines assigned at random so that a
     # de-excitation can fluoresce to a far-away wavelength
     sizes = []
     left = n_lines
-    while left > 0:
-        g = int(min(left, rng.integers(4, 9)))
-        sizes.append(g)
-        left -= g
+    if level_sizes == "heavy":
+        # In the reference a block is ALL transitions out of one source level (macroatom_solver.py:383-428, 624-670):
+        # with real Kurucz data most levels own a handful of lines, Fe-group levels hundreds to thousands.  Pareto(1.2)
+        # line counts from 4 up (2 % of the levels > 100 lines, 0.1 % > 1000), capped at 6000 lines per level, behind a few
+        # planted sizes that pin the edges of the device tables: 11 / 33 lines (33 / 99 rows in macroatom mode, 33 rows
+        # in downbranch: just past one 32-entry window, not a multiple of 8), 32 and 64 (whole windows: no padding),
+        # 100, 700 and -- on long line lists -- 6000 lines.
+        for g in (11, 32, 33, 64, 100, 700, 6000):
+            if left >= 2 * g:
+                sizes.append(g)
+                left -= g
+        while left > 0:
+            g = int(min(left, 6000, np.floor(4.0 * (1.0 - rng.random()) ** (-1.0 / 1.2))))
+            sizes.append(g)
+            left -= g
+        order = rng.permutation(len(sizes))  # (planted blocks somewhere in the tables, not all at the front)
+        sizes = [sizes[i] for i in order]
+    elif level_sizes == "uniform":
+        while left > 0:
+            g = int(min(left, rng.integers(4, 9)))
+            sizes.append(g)
+            left -= g
+    else:
+        raise ValueError(level_sizes)
     sizes = np.asarray(sizes)
     n_levels = len(sizes)
     perm = rng.permutation(n_lines)
@@ -117,6 +138,10 @@ def make_opacity_state(seed: int, geometry: st.HomologousRadial1DGeometry, n_lin
     transition_line_id = np.empty(n_trans, np.int64)
     block_edge = np.empty(n_levels + 1, np.int64)
     weights = rng.random((n_trans, 1 if shell_independent_probabilities else n_shells)) + 0.05
+    if level_sizes == "heavy":
+        # transition probabilities of a real block span many decades (A-values x Sobolev escape probabilities): most
+        # rows of a long block are below 2**-16 of the block's sum, a few carry it
+        weights *= 10.0 ** rng.normal(0.0, 2.0, (n_trans, 1))
     row = 0
     for lvl, ids in enumerate(level_lines):
         block_edge[lvl] = row
@@ -158,11 +183,13 @@ def make_problem(seed: int = 1, n_packets: int = 10_000, n_shells: int = 20, n_l
                  enable_full_relativity: bool = False, disable_line_scattering: bool = False,
                  n_bins: int = 10_000, iteration: int = 0, temperature_inner: float = 1.0e4,
                  electron_density_0: float = 1e9, log_tau_mean: float = -4.0,
-                 vpacket_spawn_range=None, shell_independent_probabilities: bool = False) -> Problem:
+                 vpacket_spawn_range=None, shell_independent_probabilities: bool = False,
+                 level_sizes: str = "uniform") -> Problem:
     geometry = make_geometry(n_shells)
     opacity = make_opacity_state(seed, geometry, n_lines, line_interaction_type,
                                  log_tau_mean=log_tau_mean, electron_density_0=electron_density_0,
-                                 shell_independent_probabilities=shell_independent_probabilities)
+                                 shell_independent_probabilities=shell_independent_probabilities,
+                                 level_sizes=level_sizes)
     packets = black_body_packets(n_packets, geometry.r_inner[0], temperature_inner, seed_offset=iteration)
     cfg = st.MonteCarloConfiguration()
     cfg.LINE_INTERACTION_TYPE = st.LINE_INTERACTION_TYPES[line_interaction_type]
@@ -175,7 +202,7 @@ def make_problem(seed: int = 1, n_packets: int = 10_000, n_shells: int = 20, n_l
         cfg.VPACKET_SPAWN_START_FREQUENCY, cfg.VPACKET_SPAWN_END_FREQUENCY = vpacket_spawn_range
     grid = make_spectrum_grid(n_bins)
     desc = (f"synthetic P={n_packets} S={n_shells} L={n_lines} {line_interaction_type} n_v={n_vpackets} "
-            f"full_rel={int(enable_full_relativity)} seed={seed}")
+            f"full_rel={int(enable_full_relativity)} seed={seed}" + (" heavy-tailed levels" if level_sizes == "heavy" else ""))
     return Problem(packets, geometry, geometry.time_explosion, opacity, cfg, grid, desc)
 
 

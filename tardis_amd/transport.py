@@ -78,22 +78,24 @@ def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, 
     out_nus, out_en = packet_collection.output_nus, packet_collection.output_energies
     in_place = all(isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous for a in (out_nus, out_en))
     vlog_capacity = None
-    for _attempt in range(2):
-        eng.reset_estimators()
-        eng.propagate()
-        eng.synchronize()
-        res = eng.get_results(out_nus if in_place else None, out_en if in_place else None, track_last_interaction=track,
-                              vpacket_log_capacity=vlog_capacity)
-        if res.vpacket_log_count <= len(res.vpacket_nus):
-            break
-        # The v-packet log was sized from a guess and overflowed (the device then drops entries): the run is
-        # deterministic, so repeat it with the capacity it asked for -- the reference returns every v-packet.
-        vlog_capacity = res.vpacket_log_count
-        eng.set_option("vpacket_log_capacity", vlog_capacity)
-    else:
-        raise RuntimeError("v-packet log overflow persisted after resizing")
-    if vlog_capacity is not None:
-        eng.set_option("vpacket_log_capacity", 0)  # back to automatic sizing
+    try:
+        for _attempt in range(2):
+            eng.reset_estimators()
+            eng.propagate()
+            eng.synchronize()
+            res = eng.get_results(out_nus if in_place else None, out_en if in_place else None, track_last_interaction=track,
+                                  vpacket_log_capacity=vlog_capacity)
+            if res.vpacket_log_count <= len(res.vpacket_nus):
+                break
+            # The v-packet log was sized from a guess and overflowed (the device then drops entries): the run is
+            # deterministic, so repeat it with the capacity it asked for -- the reference returns every v-packet.
+            vlog_capacity = res.vpacket_log_count
+            eng.set_option("vpacket_log_capacity", vlog_capacity)
+        else:
+            raise RuntimeError("v-packet log overflow persisted after resizing")
+    finally:
+        if vlog_capacity is not None:
+            eng.set_option("vpacket_log_capacity", 0)  # back to automatic sizing, whichever way the call ended
     if not in_place:
         packet_collection.output_nus[:] = res.output_nus
         packet_collection.output_energies[:] = res.output_energies

@@ -1,0 +1,124 @@
+"""GPU parity on heavy-tailed macro-atom blocks at the table shape of BASELINE.json configs[2] (20 shells x 5e5 lines).
+
+In the reference a macro-atom block is ALL transitions out of one source level (macroatom_solver.py:383-428, 624-670) and
+macro_atom_interaction walks it serially (macro_atom.py:69-99): with real Kurucz data most levels own a handful of lines,
+Fe-group levels hundreds to thousands.  `synthetic.make_problem(level_sizes="heavy")` draws such blocks (Pareto line counts,
+planted sizes 11 / 32 / 33 / 64 / 100 / 700 / 6000 lines, probabilities spread over many decades so that most rows of a long
+block are below 2**-16 of its sum).  Held here:
+
+  * the engine's own choice of kernel and every other variant against the CPU oracle: per-packet results bit-exact, work
+    counters exact (`macro_transitions` is the reference's serial count of examined rows, whatever the device searches);
+  * the device really takes the paths these blocks exist for: jumps out of blocks longer than one 32-entry window
+    (debug counter 16384) and jumps decided by the fp64 running sums because 16-bit entries tie (debug counter 32768);
+  * the small reference-generated goldens `macroatom_heavy_nv0` / `downbranch_heavy_nv2` run with every golden case in
+    test_hip_parity.py (all five variants for the v-packet one).
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from tardis_amd import state as st, synthetic
+
+pytestmark = pytest.mark.gpu
+
+EST_RTOL = 1e-11
+
+
+def _oracle(oracle, prob, pc, **kw):
+    return oracle.run(pc, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
+                      prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE, n_threads=oracle.max_threads(), **kw)
+
+
+@pytest.fixture(scope="module", params=["macroatom", "downbranch"])
+def heavy(request):
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=7, n_packets=20_000, n_shells=20, n_lines=500_000, line_interaction_type=request.param,
+                                  level_sizes="heavy")
+    sizes = np.diff(prob.opacity_state.macro_block_edge_index)
+    rows = 3 if request.param == "macroatom" else 1
+    assert sizes.max() == 6000 * rows and (sizes == 33).any() and (sizes % 8 != 0).any() and (sizes == 32 * rows).any()
+    eng = Engine(0)
+    eng.set_geometry(prob.geometry, prob.time_explosion)
+    eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+    yield eng, prob
+    eng.close()
+
+
+def _run(eng, pc, track, flags=0):
+    eng.set_option("debug_flags", flags)
+    eng.set_option("track_last_interaction", int(track))
+    eng.set_packets(pc)
+    eng.reset_estimators(); eng.propagate(); eng.synchronize()
+    eng.set_option("debug_flags", 0)
+    return eng.get_results(track_last_interaction=track)
+
+
+def test_heavy_blocks_match_oracle_on_the_automatic_kernel(heavy, oracle):
+    eng, prob = heavy
+    pc = prob.packet_collection
+    ref = _oracle(oracle, prob, pc)
+    eng.set_option("variant", -1)
+    got = _run(eng, pc, True)
+    assert eng.last_variant() == 3  # the wave kernel with lane sweeps and the compact walk: the headline's kernel
+    assert np.array_equal(got.output_nus, ref.output_nus)
+    assert np.array_equal(got.output_energies, ref.output_energies)
+    for f in st.LastInteractionTrackers.I64_FIELDS:
+        assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f)), f
+    for f in st.LastInteractionTrackers.F64_FIELDS:
+        assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f), equal_nan=True), f
+    assert_allclose(got.j_estimator, ref.j_estimator, rtol=EST_RTOL)
+    assert_allclose(got.nu_bar_estimator, ref.nu_bar_estimator, rtol=EST_RTOL)
+    assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+    assert_allclose(got.edotlu_estimator, ref.edotlu_estimator, rtol=EST_RTOL)
+    for k in ("line_visits", "events", "macro_transitions", "rng_draws", "packets"):
+        assert got.counters[k] == ref.counters[k], k
+    # long blocks dominate the walk: far more rows examined per jump than any 4-8-line level holds
+    jumps = got.counters["rng_draws"] - got.counters["events"]  # (an upper bound: direction draws are in it, too)
+    assert got.counters["macro_transitions"] > 40 * jumps
+
+
+def test_long_block_search_and_fp64_tie_break_are_executed(heavy, oracle):
+    """The two paths that only heavy-tailed blocks reach, counted on the device (counters["reserved"])."""
+    eng, prob = heavy
+    pc = prob.packet_collection.shard(0, 4)
+    ref = _oracle(oracle, prob, pc, track_last_interaction=False)
+    eng.set_option("variant", -1)
+    got = _run(eng, pc, False, flags=16384)
+    long_jumps = got.counters["reserved"]
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    got = _run(eng, pc, False, flags=32768)
+    ties = got.counters["reserved"]
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    line_interactions = ref.counters["rng_draws"] - 2 * ref.counters["events"] + ref.counters["packets"]
+    assert long_jumps > 1000 and ties > 100, (long_jumps, ties, line_interactions)
+    assert got.counters["macro_transitions"] == ref.counters["macro_transitions"]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_heavy_blocks_every_variant(heavy, oracle, variant):
+    """Lane kernel (0), group kernel (1), wave kernel with group sweeps (2) and lane sweeps (3) on a 4e3-packet slice."""
+    eng, prob = heavy
+    pc = prob.packet_collection.shard(1, 5)
+    ref = _oracle(oracle, prob, pc, track_last_interaction=False)
+    eng.set_option("variant", variant)
+    try:
+        got = _run(eng, pc, False)
+    finally:
+        eng.set_option("variant", -1)
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+    assert_allclose(got.edotlu_estimator, ref.edotlu_estimator, rtol=EST_RTOL)
+    for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
+        assert got.counters[k] == ref.counters[k], k
+
+
+@pytest.mark.parametrize("flags", [128, 8192])
+def test_heavy_blocks_fp64_walks(heavy, oracle, flags):
+    """The cross-check walks on the fp64 running sums (per-lane search: 128; cooperative group scan: 8192)."""
+    eng, prob = heavy
+    pc = prob.packet_collection.shard(2, 5)
+    ref = _oracle(oracle, prob, pc, track_last_interaction=False)
+    got = _run(eng, pc, False, flags=flags)
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    assert got.counters["macro_transitions"] == ref.counters["macro_transitions"]

@@ -58,6 +58,12 @@ CASES = {
     # Russian roulette with survivors (virtual_packet.py:221-232): optically thick lines so that tau > VPACKET_TAU_RUSSIAN occurs
     "downbranch_nv2_roulette": (dict(seed=22, n_packets=400, n_shells=8, n_lines=1500, line_interaction_type="downbranch",
                                      n_vpackets=2, log_tau_mean=-0.5), dict(SURVIVAL_PROBABILITY=0.3, ENABLE_VPACKET_TRACKING=True)),
+    # heavy-tailed macro-atom blocks (macroatom_solver.py:383-428,624-670: a block is ALL transitions out of one level):
+    # blocks of 33 ... 2100 rows, probabilities spread over many decades (most rows below 2**-16 of the block sum)
+    "macroatom_heavy_nv0": (dict(seed=31, n_packets=1200, n_shells=10, n_lines=4000, line_interaction_type="macroatom",
+                                 level_sizes="heavy", log_tau_mean=-2.0), {}),
+    "downbranch_heavy_nv2": (dict(seed=32, n_packets=800, n_shells=10, n_lines=4000, line_interaction_type="downbranch",
+                                  n_vpackets=2, level_sizes="heavy", log_tau_mean=-2.0), dict(ENABLE_VPACKET_TRACKING=True)),
     # quirk (iii) of SURVEY 8a: disable_line_scattering with non-zero tau_sobolev (real runs zero tau first, opacity_solver.py:46-56)
     "scatter_disabled_lines_tau": (dict(seed=21, n_packets=300, n_shells=6, n_lines=400, line_interaction_type="scatter",
                                         disable_line_scattering=True), {}),
