@@ -10,8 +10,9 @@ estimators, propagate every packet of this rank's shard (HIP kernels; one `tardi
 grid over the whole batch in as many launches -- epochs -- as the line-visit log needs, the estimator passes of an epoch
 beside the next one), and -- for N > 1 -- the one RCCL all-reduce of the estimator arrays
 (J, nu_bar, j_blue, Edotlu, v-hist) that an outer plasma iteration needs.  Inputs (packets, opacity tables) are
-resident in HBM before the timed region.  Weak scaling: every rank owns `--packets` packets, so an N-GPU iteration
-propagates N x packets.
+resident in HBM before the timed region.  Weak scaling (default): every rank owns `--packets` packets, so an N-GPU
+iteration propagates N x packets; `--scaling strong` shares the config's packet count among the ranks (BASELINE
+configs[3]: 1e8 packets on 8 GPUs = 1.25e7 each).
 
 Workload (default, N = 1): BASELINE.json configs[2], the configuration the metric is quoted on -- full-Kurucz-sized
 line list (5e5 lines), macroatom line interaction, 20 shells, **1e8 packets per step**, no v-packets, last-interaction
@@ -25,7 +26,10 @@ its HIP-event time, against the 8 TB/s HBM peak; the whole step beside it), `cpu
 parity-pinned C port of the reference algorithm -- timed on this box's cores on a bounded sample of the same
 workload, with the GPU-vs-CPU parity of that sample) and `boundary` (one full drop-in call
 `transport.montecarlo_transport_with_vpackets` -- host arrays in, upload, set_opacity, propagate, results out -- on
-a bounded packet count: the PCIe-inclusive rate; never `value`).
+a bounded packet count: the PCIe-inclusive rate; never `value`).  The default N = 1 line also carries `extra`: the same
+timed-step structure on (a) the headline's tables with heavy-tailed macro-atom blocks and (b) BASELINE configs[4]'s table
+shape (100 shells, macroatom, ten v-packets per interaction) at 3e6 packets, each with its own `roofline` and the parity of a
+small sample against the CPU oracle (`--no-extra` skips them).
 """
 from __future__ import annotations
 
@@ -94,6 +98,11 @@ def main():
     ap.add_argument("--level-sizes", type=str, default="uniform", choices=["uniform", "heavy"],
                     help="macro-atom block sizes of the synthetic opacity state: 'uniform' = 4-8 lines per level (rounds 1-2), "
                          "'heavy' = heavy-tailed (Pareto, up to 6000 lines = 18000 rows per block, probabilities over many decades)")
+    ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"],
+                    help="N > 1: 'weak' = every rank owns the config's packets per step (N x packets per iteration); 'strong' = "
+                         "the config's packets are shared by the N ranks (BASELINE configs[3]: 1e8 packets on 8 GPUs)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra legs of the default N = 1 line (heavy-tailed macro-atom blocks; the configs[4] table shape)")
     ap.add_argument("--no-tracking", action="store_true", help="skip the last-interaction tracker outputs")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="packets in the CPU-baseline sample (0: skip; default sized for ~15 s of CPU work)")
@@ -107,7 +116,7 @@ def main():
                     help="rank 0 writes the job's (all-reduced) J, nu_bar and per-shell sums of j_blue / Edotlu of the last step")
     args = ap.parse_args()
 
-    pg = distributed.init_from_env(backend="gloo")  # control plane only; the data-path collective is RCCL
+    pg = distributed.init_from_env()  # control plane only (TCP hub, standard library); the data-path collective is RCCL
     if pg.world_size != args.gpus:
         if pg.rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={pg.world_size}; using WORLD_SIZE", file=sys.stderr)
@@ -124,7 +133,9 @@ def main():
         kw["line_interaction_type"] = args.mode
     if args.vpackets is not None:
         kw["n_vpackets"] = args.vpackets
-    if args.config in (4, 5) and args.packets is None:
+    if args.scaling == "strong":
+        kw["n_packets"] //= n_gpus  # the quoted packet count is the job's: every rank takes its share
+    elif args.config in (4, 5) and args.packets is None:
         kw["n_packets"] //= 8  # those configs quote the 8-GPU total
     P = int(kw.pop("n_packets"))
     # opacities, geometry, configuration on the host (same on every rank); the packets never exist on the host
@@ -145,7 +156,7 @@ def main():
     eng.create_blackbody_packets(P * n_gpus, radius, T_INNER, first=pg.rank * P, count=P)
     rccl_ok = distributed.setup_engine_comm(eng, pg)
     if not rccl_ok and pg.rank == 0:
-        print("warning: no RCCL communicator; the estimators are all-reduced on the host through gloo", file=sys.stderr)
+        print("warning: no RCCL communicator; the estimators are summed on the host through the control plane", file=sys.stderr)
 
     def step():
         eng.reset_estimators()
@@ -189,7 +200,7 @@ def main():
     mode = kw["line_interaction_type"]
     out = {
         "metric": "packets/sec", "value": value, "unit": "packets/s", "n_gpus": n_gpus, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[{args.config - 1}]: {P} packets/GPU/step, "
@@ -200,36 +211,13 @@ def main():
                         f"device black-body source (T_inner = {T_INNER:g} K)",
             "packets_per_gpu": P, "n_shells": kw["n_shells"], "n_lines": kw["n_lines"],
             "line_interaction_type": mode, "n_vpackets": kw.get("n_vpackets", 0),
-            "parallelism": (f"packet-sharded x{n_gpus}, " + ("RCCL all-reduce of estimators per step" if rccl_ok
-                            else "host (gloo) all-reduce of estimators per step: RCCL communicator unavailable")) if n_gpus > 1 else "single GPU",
+            "parallelism": (f"packet-sharded x{n_gpus} ({args.scaling} scaling: {P} packets per GPU and step, {P * n_gpus} per iteration), "
+                            + ("RCCL all-reduce of estimators per step" if rccl_ok
+                               else "host-side sum of estimators per step through the control plane: RCCL communicator unavailable")) if n_gpus > 1 else "single GPU",
         },
     }
     if pg.rank == 0:
-        # dominant kernel = the propagation kernel; its launches of one step are timed with HIP events on the streams they run on
-        launches = max(ktimes["launches"], 1)
-        variant = eng.last_variant()  # (the engine's automatic choice unless --variant was given)
-        wave = variant in (2, 3, 4)
-        dominant = {0: "propagate_lane_kernel", 1: "propagate_group_kernel", 2: "propagate_wave_kernel (group sweeps)",
-                    3: "propagate_wave_kernel (lane sweeps)", 4: "propagate_wave_kernel (volley queue)"}.get(variant, f"variant {variant}")
-        kernel_ms = ktimes["propagate_ms"] / launches
-        # the dominant kernel's own algorithmic bytes (see algorithmic_bytes) over its HIP-event duration
-        bytes_per_launch = algorithmic_bytes(counters, "propagate" if wave else "step") / launches
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        step_bytes = algorithmic_bytes(counters, "step")
-        step_achieved = step_bytes / (last_ms * 1e-3) / 1e9
-        traffic = measured_traffic(args, P, launches)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": f"{dominant} (dominant kernel of a step)", "kernel_ms": kernel_ms,
-                           "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-                           "note": "kernel_ms = mean HIP-event duration of the step's propagation launches (the epochs of one "
-                                   "tardis_mc_propagate call, back to back on the engine's stream; the estimator passes of an epoch run "
-                                   "beside the next one on a second stream)",
-                           "step": {"algorithmic_bytes": step_bytes, "device_ms": last_ms, "achieved": step_achieved,
-                                    "frac": step_achieved / HBM_PEAK_GBS, "seed_kernel_ms": ktimes["seed_ms"],
-                                    "estimator_passes_ms": ktimes.get("estimator_ms", 0.0),
-                                    "note": "all kernels of one iteration: launch preparation, propagation, line-estimator passes"},
-                           "per_packet": {k: counters[k] / max(P, 1) for k in ("line_visits", "events", "macro_transitions", "rng_draws")}}
+        out["roofline"] = roofline_block(eng, counters, ktimes, last_ms, P, measured_traffic(args, P, max(ktimes["launches"], 1)))
         if n_gpus == 1:
             n_cpu = args.cpu_sample if args.cpu_sample is not None else default_cpu_sample(kw)
             if n_cpu > 0:
@@ -237,10 +225,87 @@ def main():
             n_b = args.boundary_packets if args.boundary_packets is not None else min(P, 10_000_000)
             if n_b > 0:
                 out["boundary"] = boundary_call(prob, eng, n_b, not args.no_tracking)
+    eng.close()  # (frees the line-visit log before the extra legs allocate theirs)
+    default_line = (n_gpus == 1 and args.config == 3 and args.level_sizes == "uniform" and not args.option and not args.no_tracking
+                    and all(v is None for v in (args.packets, args.lines, args.shells, args.mode, args.vpackets, args.variant)))
+    if pg.rank == 0 and default_line and not args.no_extra:
+        dev = pg.local_rank if args.all_on_device is None else args.all_on_device
+        # (a) the headline's tables with heavy-tailed macro-atom blocks (what real atomic data looks like: a block is ALL
+        #     transitions out of a level), same packet count; (b) BASELINE configs[4]'s table shape -- 100 shells, macroatom,
+        #     ten v-packets per interaction -- at a packet count that keeps the whole run within minutes
+        out["extra"] = {
+            "heavy_tail": extra_leg(dev, "configs[2] tables, heavy-tailed blocks", synthetic.BASELINE_CONFIGS[3], P, 2, 1, "heavy", 20_000, True),
+            "config5_shape": extra_leg(dev, "configs[4] table shape", synthetic.BASELINE_CONFIGS[5], 3_000_000, 2, 1, "uniform", 3_000, True),
+        }
     if pg.rank == 0:
         print(json.dumps(out), flush=True)
-    eng.close()
     pg.destroy()
+
+
+def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, traffic) -> dict:
+    """`roofline` of one workload: the dominant kernel = the propagation kernel; its launches of one step are timed with HIP
+    events on the stream they run on."""
+    launches = max(ktimes["launches"], 1)
+    variant = eng.last_variant()  # (the engine's automatic choice unless --variant was given)
+    wave = variant in (2, 3, 4)
+    dominant = {0: "propagate_lane_kernel", 1: "propagate_group_kernel", 2: "propagate_wave_kernel (group sweeps)",
+                3: "propagate_wave_kernel (lane sweeps)", 4: "propagate_wave_kernel (volley queue)"}.get(variant, f"variant {variant}")
+    kernel_ms = ktimes["propagate_ms"] / launches
+    # the dominant kernel's own algorithmic bytes (see algorithmic_bytes) over its HIP-event duration
+    bytes_per_launch = algorithmic_bytes(counters, "propagate" if wave else "step") / launches
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    step_bytes = algorithmic_bytes(counters, "step")
+    step_achieved = step_bytes / (last_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": f"{dominant} (dominant kernel of a step)", "kernel_ms": kernel_ms,
+            "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "note": "kernel_ms = mean HIP-event duration of the step's propagation launches (the epochs of one "
+                    "tardis_mc_propagate call, back to back on the engine's stream; the estimator passes of an epoch run "
+                    "beside the next one on a second stream); macro-atom term of the byte model: min(8 B x rows examined, "
+                    "80 B x jumps), see walk_bytes()",
+            "step": {"algorithmic_bytes": step_bytes, "device_ms": last_ms, "achieved": step_achieved,
+                     "frac": step_achieved / HBM_PEAK_GBS, "seed_kernel_ms": ktimes["seed_ms"],
+                     "estimator_passes_ms": ktimes.get("estimator_ms", 0.0),
+                     "note": "all kernels of one iteration: launch preparation, propagation, line-estimator passes"},
+            "per_packet": {k: counters[k] / max(P, 1) for k in ("line_visits", "events", "macro_transitions", "rng_draws",
+                                                                 "vpackets", "vpacket_line_visits")}}
+
+
+def extra_leg(device: int, name: str, kw: dict, P: int, steps: int, warmup: int, level_sizes: str, cpu_sample: int, track: bool) -> dict:
+    """One more workload on the same GPU after the headline's engine is closed (N = 1 only): same timed-step structure,
+    its own `roofline`, and the parity of a small sample against the CPU oracle.  Never `value`."""
+    t_build = time.perf_counter()
+    kw = dict(kw)
+    kw.pop("n_packets", None)
+    prob = synthetic.make_problem(seed=1, n_packets=1, level_sizes=level_sizes, **kw)
+    eng = Engine(device)
+    eng.set_option("track_last_interaction", int(track))
+    eng.set_geometry(prob.geometry, prob.time_explosion)
+    eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+    radius = float(prob.geometry.r_inner[0])
+    eng.create_blackbody_packets(P, radius, T_INNER, first=0, count=P)
+    t_build = time.perf_counter() - t_build
+    for _ in range(warmup):
+        eng.reset_estimators(); eng.propagate()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.reset_estimators(); eng.propagate()
+    eng.synchronize()
+    elapsed = time.perf_counter() - t0
+    last_ms, ktimes, counters = eng.last_propagate_ms(), eng.last_kernel_times(), eng.last_counters()
+    sizes = np.diff(prob.opacity_state.macro_block_edge_index)
+    leg = {"workload": f"{name}: {P} packets/step, {kw['n_shells']} shells, {kw['n_lines']} lines, {kw['line_interaction_type']}, "
+                       f"{kw.get('n_vpackets', 0)} v-packets, tracking {'on' if track else 'off'}, macro-atom blocks "
+                       f"{level_sizes} (rows per block: median {int(np.median(sizes))}, max {int(sizes.max())})",
+           "value": P * steps / elapsed, "unit": "packets/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+           "setup_s": t_build, "roofline": roofline_block(eng, counters, ktimes, last_ms, P, None)}
+    if cpu_sample > 0:
+        leg["cpu_sample"] = cpu_baseline(prob, eng, P, radius, min(cpu_sample, P), single_thread=False)
+    eng.close()
+    return leg
 
 
 def measured_traffic(args, P: int, launches: int):
@@ -272,7 +337,7 @@ def default_cpu_sample(kw: dict) -> int:
     return 800_000 if heavy else 10_000_000
 
 
-def cpu_baseline(prob, eng, P: int, radius: float, n_sample: int) -> dict:
+def cpu_baseline(prob, eng, P: int, radius: float, n_sample: int, single_thread: bool = True) -> dict:
     """Time the CPU oracle (parity-pinned C port of the reference algorithm, OpenMP over packets) on the first
     n_sample packets of the workload, and report the parity of the GPU result on that sample."""
     from oracle import oracle
@@ -292,7 +357,8 @@ def cpu_baseline(prob, eng, P: int, radius: float, n_sample: int) -> dict:
     n1 = max(n // 8, 1)
     sub1 = sub.shard(0, max(n // n1, 1))
     t0 = time.perf_counter()
-    oracle.run(sub1, *a, math_mode=oracle.MATH_PORTABLE, n_threads=1, track_last_interaction=False)
+    if single_thread:
+        oracle.run(sub1, *a, math_mode=oracle.MATH_PORTABLE, n_threads=1, track_last_interaction=False)
     dt_1 = time.perf_counter() - t0
     # GPU result on the same sample (per-packet results do not depend on batching)
     eng.reset_estimators()
@@ -302,16 +368,18 @@ def cpu_baseline(prob, eng, P: int, radius: float, n_sample: int) -> dict:
     t_sim = sub.time_of_simulation
     ha = spectrum.emitted_luminosity_histogram(got.output_nus, got.output_energies, t_sim, prob.spectrum_frequency_grid)
     hb = spectrum.emitted_luminosity_histogram(ref.output_nus, ref.output_energies, t_sim, prob.spectrum_frequency_grid)
+    one = f"; 1 thread on {sub1.number_of_packets} packets: {sub1.number_of_packets / dt_1:.0f} packets/s" if single_thread else ""
     return {
         "value": n / dt_all, "unit": "packets/s", "cores": threads, "kind": "port",
         "sample": f"first {n} packets of the workload, CPU oracle (C port of the reference algorithm, -O2 IEEE-strict, "
-                  f"OpenMP {threads} threads) {dt_all:.1f} s; 1 thread on {sub1.number_of_packets} packets: "
-                  f"{sub1.number_of_packets / dt_1:.0f} packets/s",
-        "single_thread_value": sub1.number_of_packets / dt_1,
+                  f"OpenMP {threads} threads) {dt_all:.1f} s" + one,
+        "single_thread_value": sub1.number_of_packets / dt_1 if single_thread else None,
         "spectrum_rel_l2_gpu_vs_cpu": spectrum.relative_l2(ha, hb),
         "per_packet_bit_exact": bool(np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)),
         "max_rel_diff_J": float(np.max(np.abs(got.j_estimator - ref.j_estimator) / np.abs(ref.j_estimator))),
         "max_rel_diff_nu_bar": float(np.max(np.abs(got.nu_bar_estimator - ref.nu_bar_estimator) / np.abs(ref.nu_bar_estimator))),
+        "vpacket_spectrum_rel_l2_gpu_vs_cpu": (spectrum.relative_l2(got.v_packets_energy_hist, ref.v_packets_energy_hist)
+                                               if ref.counters["vpackets"] > 0 else None),
     }
 
 

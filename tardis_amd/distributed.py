@@ -2,15 +2,54 @@
 per Monte Carlo iteration.
 
 The data-path collective on GPUs is RCCL, called inside the engine on its own stream
-(tardis_mc_allreduce_estimators).  ``torch.distributed`` is used only as the control plane: rendezvous from the
-launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT), broadcast of the 128-byte
-RCCL unique id, barriers, and max-over-ranks of timings.  The same helpers run on CPU with the gloo backend
-(world_size-2 tests).
+(tardis_mc_allreduce_estimators).  What is left for the host is a control plane: rendezvous from the launcher's
+environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT, as ``python -m torch.distributed.run`` sets
+them), broadcast of the 128-byte RCCL unique id, barriers, max-over-ranks of timings, and -- only as the fall-back when
+no RCCL communicator exists -- a host-side sum of the estimator arrays.  That is a few small messages per iteration, so
+it runs over plain TCP sockets from the standard library (rank 0 is the hub): the package imports neither PyTorch nor
+any other framework.  The same code runs on CPU (world_size-2 tests).
+
+Rendezvous on one node.  The launcher's agent already owns MASTER_PORT (its own store), so rank 0 binds an ephemeral
+port on MASTER_ADDR and publishes it in a small file named after (MASTER_PORT, the launcher's pid -- every rank is a
+child of the same agent); the other ranks poll for it.  ``TARDIS_AMD_CONTROL_PORT`` pins the port instead (ranks
+started by hand).
 """
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass
+import socket
+import struct
+import tempfile
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HELLO = b"TMCG"
+_CONNECT_TIMEOUT_S = 300.0
+
+
+def _send_msg(sock: socket.socket, payload: bytes) -> None:
+    sock.sendall(struct.pack("<Q", len(payload)))
+    if payload:
+        sock.sendall(payload)
+
+
+def _recv_exact(sock: socket.socket, n: int) -> bytes:
+    buf = bytearray(n)
+    view = memoryview(buf)
+    got = 0
+    while got < n:
+        k = sock.recv_into(view[got:], n - got)
+        if k == 0:
+            raise ConnectionError("control plane: peer closed the connection")
+        got += k
+    return bytes(buf)
+
+
+def _recv_msg(sock: socket.socket) -> bytes:
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n) if n else b""
 
 
 @dataclass
@@ -18,62 +57,150 @@ class ProcessGroup:
     rank: int = 0
     world_size: int = 1
     local_rank: int = 0
-    dist: object = None  # torch.distributed module when world_size > 1
+    _peers: list = field(default_factory=list, repr=False)   # rank 0: sockets of ranks 1..W-1 (index r-1)
+    _hub: object = field(default=None, repr=False)            # ranks > 0: socket to rank 0
+    _rdzv_file: str | None = field(default=None, repr=False)
 
     @property
     def is_distributed(self) -> bool:
         return self.world_size > 1
 
-    def barrier(self):
-        if self.is_distributed:
-            self.dist.barrier()
+    # -- the one primitive: every rank contributes a message, rank 0 reduces, every rank gets the result
+    def _allreduce_bytes(self, payload: bytes, reduce) -> bytes:
+        if not self.is_distributed:
+            return reduce([payload])
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(s) for s in self._peers]
+            out = reduce(parts)
+            for s in self._peers:
+                _send_msg(s, out)
+            return out
+        _send_msg(self._hub, payload)
+        return _recv_msg(self._hub)
 
-    def broadcast_bytes(self, payload: bytes | None, src: int = 0) -> bytes:
+    def barrier(self):
+        self._allreduce_bytes(b"", lambda parts: b"")
+
+    def broadcast_bytes(self, payload: bytes | None, src: int = 0) -> bytes | None:
+        """The bytes of rank ``src`` on every rank (None travels as None)."""
         if not self.is_distributed:
             return payload
-        box = [payload]
-        self.dist.broadcast_object_list(box, src=src)
-        return box[0]
+        mine = (b"\x01" + payload) if (self.rank == src and payload is not None) else (b"\x00" if self.rank == src else b"")
+        out = self._allreduce_bytes(mine, lambda parts: parts[src])
+        return out[1:] if out[:1] == b"\x01" else None
 
     def max_float(self, value: float) -> float:
-        if not self.is_distributed:
-            return value
-        import torch
-
-        t = torch.tensor([value], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t[0])
+        out = self._allreduce_bytes(struct.pack("<d", float(value)),
+                                    lambda parts: struct.pack("<d", max(struct.unpack("<d", p)[0] for p in parts)))
+        return struct.unpack("<d", out)[0]
 
     def sum_arrays_(self, arrays):
-        """In-place sum over ranks of host numpy arrays (control-plane / CPU path; GPUs use RCCL in the engine)."""
+        """In-place sum over ranks of host float64 arrays, added in rank order (control-plane / CPU path; GPUs use RCCL
+        in the engine)."""
         if not self.is_distributed:
             return arrays
-        import torch
-
         for a in arrays:
-            t = torch.from_numpy(a)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            if a.dtype != np.float64 or not a.flags.c_contiguous:
+                raise TypeError("sum_arrays_ wants C-contiguous float64 arrays")
+
+            def reduce(parts):
+                acc = np.frombuffer(parts[0], dtype=np.float64).copy()
+                for p in parts[1:]:
+                    acc += np.frombuffer(p, dtype=np.float64)
+                return acc.tobytes()
+
+            out = self._allreduce_bytes(a.tobytes(), reduce)
+            a[...] = np.frombuffer(out, dtype=np.float64).reshape(a.shape)
         return arrays
 
     def destroy(self):
-        if self.is_distributed and self.dist.is_initialized():
-            self.dist.destroy_process_group()
+        try:
+            if self.is_distributed:
+                self.barrier()  # nobody closes while another rank still waits for an answer
+        except OSError:
+            pass
+        for s in self._peers + ([self._hub] if self._hub else []):
+            try:
+                s.close()
+            except OSError:
+                pass
+        self._peers, self._hub = [], None
+        if self._rdzv_file:
+            try:
+                os.unlink(self._rdzv_file)
+            except OSError:
+                pass
+            self._rdzv_file = None
 
 
-def init_from_env(backend: str = "gloo") -> ProcessGroup:
-    """Join the job described by the launcher's environment (torch.distributed.run sets it)."""
+def _rendezvous_path(master_port: str) -> str:
+    return os.path.join(tempfile.gettempdir(), f"tardis_amd_ctl_{master_port}_{os.getppid()}")
+
+
+def init_from_env(backend: str = "tcp") -> ProcessGroup:
+    """Join the job described by the launcher's environment (``python -m torch.distributed.run`` sets it; so can a shell
+    loop).  ``backend`` is accepted for interface stability; the control plane is always the TCP hub described above."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world <= 1:
-        return ProcessGroup(0, 1, local_rank, None)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    import torch.distributed as dist
-
-    if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return ProcessGroup(rank, world, local_rank, dist)
+        return ProcessGroup(0, 1, local_rank)
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    master_port = os.environ.get("MASTER_PORT", "29533")
+    fixed = os.environ.get("TARDIS_AMD_CONTROL_PORT")
+    token = struct.pack("<4sqq", _HELLO, int(master_port), world)
+    deadline = time.monotonic() + _CONNECT_TIMEOUT_S
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, int(fixed) if fixed else 0))
+        srv.listen(world)
+        path = None
+        if not fixed:
+            path = _rendezvous_path(master_port)
+            tmp = f"{path}.{os.getpid()}"
+            with open(tmp, "w") as f:
+                f.write(str(srv.getsockname()[1]))
+            os.replace(tmp, path)  # (atomic: a reader sees the old content or the new one)
+        peers: list = [None] * (world - 1)
+        srv.settimeout(1.0)
+        while any(p is None for p in peers):
+            if time.monotonic() > deadline:
+                raise TimeoutError("control plane: not every rank connected to rank 0")
+            try:
+                c, _ = srv.accept()
+            except socket.timeout:
+                continue
+            c.settimeout(30.0)
+            try:
+                hello = _recv_msg(c)
+                r = struct.unpack("<q", hello[len(token):])[0] if hello[:len(token)] == token else -1
+            except (OSError, struct.error):
+                r = -1
+            if not (1 <= r < world) or peers[r - 1] is not None:
+                c.close()  # (a stray connection, or a rank of another job that read a stale file)
+                continue
+            c.settimeout(None)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            _send_msg(c, token)
+            peers[r - 1] = c
+        srv.close()
+        return ProcessGroup(0, world, local_rank, peers, None, path)
+    while True:
+        if time.monotonic() > deadline:
+            raise TimeoutError("control plane: rank 0 not reachable")
+        try:
+            port = int(fixed) if fixed else int(open(_rendezvous_path(master_port)).read())
+            s = socket.create_connection((addr, port), timeout=5.0)
+            s.settimeout(30.0)
+            _send_msg(s, token + struct.pack("<q", rank))
+            if _recv_msg(s) != token:  # (something else listens there: a stale file of an earlier job)
+                raise ConnectionError("control plane: wrong peer")
+            s.settimeout(None)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            return ProcessGroup(rank, world, local_rank, [], s, None)
+        except (OSError, ValueError):
+            time.sleep(0.05)
 
 
 def shard_bounds(n_items: int, rank: int, world_size: int) -> tuple[int, int]:

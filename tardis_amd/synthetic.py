@@ -37,19 +37,26 @@ class Problem:
 
 
 def black_body_packets(n_packets: int, radius: float, temperature: float, base_seed: int = DEFAULT_BASE_SEED,
-                       seed_offset: int = 0, l_samples: int = 1000) -> st.PacketCollection:
-    """Sample a packet collection at the photosphere (see module docstring for the reference lines)."""
+                       seed_offset: int = 0, l_samples: int = 1000, legacy_random_state=None) -> st.PacketCollection:
+    """Sample a packet collection at the photosphere (see module docstring for the reference lines).
+
+    ``legacy_random_state``: the reference's ``legacy_mode_enabled`` source (what its own integration test runs,
+    tests/test_montecarlo_main_loop.py:14-60) draws the five Planck uniforms and the direction uniforms from NumPy's GLOBAL
+    legacy stream (black_body.py:172,201), seeded once with ``base_seed`` when the source is constructed (base.py:48-59) and
+    never re-seeded, so consecutive iterations continue it; only the packet seeds still come from PCG64(base_seed +
+    iteration).  Pass one ``np.random.RandomState(base_seed)`` for the whole run to reproduce that."""
     rng = np.random.default_rng(base_seed + seed_offset)
     packet_seeds = rng.choice(MAX_SEED_VAL, n_packets, replace=True)
     radii = np.ones(n_packets) * radius
     # Planck sampler (Carter & Cashwell 1975 via Bjorkman & Wood 2001)
     l_array = np.cumsum(np.arange(1, l_samples, dtype=np.float64) ** -4)
     l_coef = np.pi**4 / 90.0
-    xis = rng.random((5, n_packets))
+    draws = legacy_random_state.random_sample if legacy_random_state is not None else rng.random
+    xis = draws((5, n_packets))
     l_min = l_array.searchsorted(xis[0] * l_coef) + 1.0
     x = -np.log(np.prod(xis[1:], 0)) / l_min
     nus = x * (st.K_BOLTZMANN * temperature) / st.H_PLANCK
-    mus = np.sqrt(rng.random(n_packets))
+    mus = np.sqrt(draws(n_packets))
     energies = np.ones(n_packets) / n_packets
     luminosity = 4 * np.pi * st.SIGMA_SB * radius**2 * temperature**4
     return st.PacketCollection(radii, nus, mus, energies, packet_seeds, luminosity)

@@ -1,4 +1,6 @@
-"""Worker of tests/test_distributed_cpu.py: one rank of a world_size-2 gloo job (launched by torch.distributed.run).
+"""Worker of tests/test_distributed_cpu.py: one rank of a world_size-2 job (launched by torch.distributed.run or by hand);
+argv[2] picks the control plane: "tcp" = the product's own (tardis_amd.distributed, standard library only), "gloo" = the
+torch.distributed twin of tests/_gloo_group.py.
 
 Exercises the host-side multi-GPU plumbing on CPU: environment rendezvous, packet sharding by index, disjoint
 per-packet output slices and the sum-all-reduce of the estimator arrays.  The per-shard transport itself is run by
@@ -17,7 +19,14 @@ from tardis_amd import distributed, synthetic  # noqa: E402
 
 def main():
     out_path = sys.argv[1]
-    pg = distributed.init_from_env(backend="gloo")
+    backend = sys.argv[2] if len(sys.argv) > 2 else "tcp"
+    if backend == "gloo":
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from _gloo_group import GlooGroup
+        pg = GlooGroup()
+    else:
+        pg = distributed.init_from_env()
+        assert "torch" not in sys.modules  # the product's control plane is standard library only
     assert pg.world_size == 2
     prob = synthetic.make_problem(seed=31, n_packets=3001, n_shells=6, n_lines=900, line_interaction_type="macroatom")
     pc = prob.packet_collection
@@ -32,6 +41,8 @@ def main():
     payload = pg.broadcast_bytes(b"x" * 128 if pg.rank == 0 else None, src=0)
     assert payload == b"x" * 128
     assert pg.max_float(float(pg.rank)) == 1.0
+    assert pg.broadcast_bytes(b"from one" if pg.rank == 1 else None, src=1) == b"from one"
+    assert pg.broadcast_bytes(None, src=0) is None
 
     # communicator set-up: every rank learns the same verdict, whichever rank the failure happens on
     class FakeEngine:

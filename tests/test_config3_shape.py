@@ -87,6 +87,43 @@ def test_config3_shape_every_cooperative_variant(config3, oracle, variant):
         assert got.counters[k] == ref.counters[k], k
 
 
+def test_config3_shape_full_relativity(config3, oracle):
+    """enable_full_relativity at the configs[2] table shape (set_packet_props_full_relativity, the relativistic Doppler factors,
+    angle aberration, packet_propagation.py:285-318; frame_transformations.py:12-109): the engine picks the wave kernel with
+    group sweeps (the lane sweeps' no-stop bounds are those of partial relativity)."""
+    import copy
+    eng, prob = config3
+    cfg = copy.copy(prob.montecarlo_configuration)
+    cfg.ENABLE_FULL_RELATIVITY = True
+    pc = prob.packet_collection.shard(0, 2)
+    ref = oracle.run(pc, prob.geometry, prob.time_explosion, prob.opacity_state, cfg, prob.spectrum_frequency_grid,
+                     math_mode=oracle.MATH_PORTABLE, n_threads=oracle.max_threads())
+    eng.set_config(cfg, prob.spectrum_frequency_grid)
+    try:
+        eng.set_option("variant", -1)
+        eng.set_option("track_last_interaction", 1)
+        eng.set_packets(pc)
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        got = eng.get_results(track_last_interaction=True)
+        assert eng.last_variant() == 2
+    finally:
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    for f in st.LastInteractionTrackers.I64_FIELDS:
+        assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f)), f
+    for f in st.LastInteractionTrackers.F64_FIELDS:
+        assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f), equal_nan=True), f
+    assert_allclose(got.j_estimator, ref.j_estimator, rtol=EST_RTOL)
+    assert_allclose(got.nu_bar_estimator, ref.nu_bar_estimator, rtol=EST_RTOL)
+    assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+    assert_allclose(got.edotlu_estimator, ref.edotlu_estimator, rtol=EST_RTOL)
+    for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
+        assert got.counters[k] == ref.counters[k], k
+    # and it is a different problem from the partial-relativity one, not a no-op switch
+    part = _oracle(oracle, prob, pc)
+    assert not np.array_equal(part.output_nus, ref.output_nus)
+
+
 def test_config3_full_size_properties(config3, oracle):
     """2e7 packets of the configs[2] workload (a fifth of its 1e8; the bench runs the full count): every packet terminates,
     the counters add up, a different chunking reproduces the run bit for bit per packet, and the first 1e5 packets equal

@@ -1,11 +1,14 @@
-"""world_size-2 gloo test of the multi-process path: packets shard by index with no data-path
-collective for per-packet outputs, and ONE sum-all-reduce joins the estimator arrays."""
+"""world_size-2 tests of the multi-process path on CPU: packets shard by index with no data-path
+collective for per-packet outputs, and ONE sum-all-reduce joins the estimator arrays.  Run over the product's own
+control plane (tardis_amd.distributed: TCP hub, standard library only) and over torch.distributed's gloo backend
+(tests/_gloo_group.py), launched by torch.distributed.run the way the driver launches bench.py, and once by hand."""
 import os
 import socket
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 from numpy.testing import assert_allclose
 
 from tardis_amd import distributed, synthetic
@@ -30,13 +33,23 @@ def test_shard_bounds_partition():
             assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
 
 
-def test_two_rank_gloo_job_matches_single_process(tmp_path, oracle):
+@pytest.mark.parametrize("backend,launcher", [("tcp", "torchrun"), ("gloo", "torchrun"), ("tcp", "by hand")])
+def test_two_rank_job_matches_single_process(tmp_path, oracle, backend, launcher):
     out = str(tmp_path / "dist")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"), out]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
+    worker = os.path.join(ROOT, "tests", "_dist_worker.py")
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), worker, out, backend]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:  # two processes started by hand: RANK / WORLD_SIZE and a pinned control port
+        env.update(WORLD_SIZE="2", MASTER_PORT=str(_free_port()), TARDIS_AMD_CONTROL_PORT=str(_free_port()))
+        procs = [subprocess.Popen([sys.executable, worker, out, backend], env=dict(env, RANK=str(k), LOCAL_RANK=str(k)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k in (1, 0)]
+        for p in procs:
+            o, _ = p.communicate(timeout=600)
+            assert p.returncode == 0, o
     prob = synthetic.make_problem(seed=31, n_packets=3001, n_shells=6, n_lines=900, line_interaction_type="macroatom")
     ref = oracle.run(prob.packet_collection, prob.geometry, prob.time_explosion, prob.opacity_state,
                      prob.montecarlo_configuration, prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE)

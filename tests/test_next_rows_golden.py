@@ -51,6 +51,23 @@ def test_host_sampler_and_oracle_streams_match_the_reference_source(name):
     assert np.array_equal(np.sqrt(z), g["initial_mus"])
 
 
+def test_host_sampler_legacy_mode_matches_the_reference_source():
+    """legacy_mode_enabled (what the reference's own integration test uses, tests/test_montecarlo_main_loop.py:14-60): Planck
+    and direction uniforms from the global legacy MT19937 stream, seeded once, continued over two iterations."""
+    state = None
+    for it in (0, 1):
+        g = _load(f"legacy_packet_source_iter{it}")
+        if state is None:
+            state = np.random.RandomState(int(g["base_seed"]))
+        pc = synthetic.black_body_packets(int(g["n"]), float(g["radius"]), float(g["temperature"]), base_seed=int(g["base_seed"]),
+                                          seed_offset=it, legacy_random_state=state)
+        assert np.array_equal(pc.packet_seeds, g["packet_seeds"])
+        assert np.array_equal(pc.initial_mus, g["initial_mus"])
+        assert_allclose(pc.initial_nus, g["initial_nus"], rtol=1e-15, atol=0)
+    # and the legacy stream really is another stream than the PCG64 one
+    assert not np.array_equal(synthetic.black_body_packets(777, 1.2e15, 9974.0).initial_mus, _load("legacy_packet_source_iter0")["initial_mus"])
+
+
 @pytest.mark.parametrize("name", RADFIELD_CASES)
 def test_radfield_oracle_matches_the_reference_solver(name):
     g = _load(name)

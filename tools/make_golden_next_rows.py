@@ -40,6 +40,17 @@ for name, n, radius, temperature, base_seed, seed_offset in (
                         radiation_field_luminosity=pc.radiation_field_luminosity)
     print(name, n, pc.initial_nus[:2], pc.packet_seeds[:2])
 
+# ---- legacy_mode_enabled source (black_body.py:172,201: the Planck and direction uniforms from NumPy's GLOBAL legacy stream,
+# seeded at construction, base.py:48-59, and continued across iterations): two consecutive iterations of one source
+src = ref.BlackBodySimpleSource(Q(1.2e15, "cm"), Q(9974.0, "K"), base_seed=23111963, legacy_mode_enabled=True)
+for it in (0, 1):
+    pc = src.create_packets(777, seed_offset=it)
+    np.savez_compressed(os.path.join(OUT, f"legacy_packet_source_iter{it}.npz"), n=777, radius=1.2e15, temperature=9974.0,
+                        base_seed=23111963, seed_offset=it, initial_radii=pc.initial_radii, initial_nus=pc.initial_nus,
+                        initial_mus=pc.initial_mus, initial_energies=pc.initial_energies, packet_seeds=pc.packet_seeds,
+                        radiation_field_luminosity=pc.radiation_field_luminosity)
+    print("legacy", it, pc.initial_nus[:2], pc.initial_mus[:2])
+
 # ---- radiation field
 for name, args, window, w_eps in (
         ("radfield_downbranch", dict(seed=9, n_packets=6000, n_shells=6, n_lines=500, line_interaction_type="downbranch"), False, 1e-10),
