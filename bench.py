@@ -396,9 +396,33 @@ def boundary_call(prob, eng, n: int, track: bool) -> dict:
                                                  prob.spectrum_frequency_grid, trackers, cfg.NUMBER_OF_VPACKETS, False, None,
                                                  engine=eng)
     dt = time.perf_counter() - t0
-    return {"packets": n, "ms": 1e3 * dt, "packets_per_s": n / dt, "device_ms": transport.montecarlo_transport_with_vpackets.last_kernel_ms,
-            "note": "transport.montecarlo_transport_with_vpackets on host arrays (upload, set_opacity, propagate, get_results incl. "
-                    "last-interaction trackers and [L,S] estimators); PCIe-inclusive, not `value`"}
+    out = {"packets": n, "ms": 1e3 * dt, "packets_per_s": n / dt, "device_ms": transport.montecarlo_transport_with_vpackets.last_kernel_ms,
+           "note": "transport.montecarlo_transport_with_vpackets on host arrays (upload, set_opacity, propagate, get_results incl. "
+                   "last-interaction trackers and [L,S] estimators); PCIe-inclusive, not `value`"}
+    # the resident outer iteration (simulation/base.py:419-490 through MCTransportSolverHIP(resident=True)): packets drawn on the
+    # device, opacity tables uploaded (first iteration) or reused (same opacity object), propagation, spectrum + luminosities
+    # and the radiation field (T_rad, W and the [L,S] j_blues the plasma step reads) reduced on the device
+    geo = prob.geometry
+    volume = 4.0 / 3.0 * np.pi * (geo.r_outer**3 - geo.r_inner**3)
+    mode = {0: "scatter", 1: "downbranch", 2: "macroatom"}[int(cfg.LINE_INTERACTION_TYPE)]
+    solver = transport.MCTransportSolverHIP(prob.spectrum_frequency_grid, cfg, line_interaction_type=mode, resident=True, engine=eng,
+                                            enable_last_interaction_tracking=track)
+    res = []
+    for iteration in (0, 1):
+        t0 = time.perf_counter()
+        ts = solver.initialize_transport_state(None, geo, prob.opacity_state, prob.time_explosion, int(cfg.NUMBER_OF_VPACKETS),
+                                               n_packets=n, iteration=iteration, temperature_inner=T_INNER)
+        solver.run(ts)
+        sp = ts.packet_spectrum(prob.spectrum_frequency_grid)
+        rf = ts.radiation_field(volume)
+        dt = time.perf_counter() - t0
+        res.append({"ms": 1e3 * dt, "packets_per_s": n / dt, "device_ms": transport.montecarlo_transport_with_vpackets.last_kernel_ms,
+                    "emitted_luminosity_fraction": sp["emitted_luminosity"] * ts.time_of_simulation,
+                    "t_rad_inner": float(rf["t_radiative"][0])})
+    out["resident"] = {"first_iteration_with_table_upload": res[0], "next_iteration_same_opacity": res[1],
+                       "note": "MCTransportSolverHIP(resident=True): device packet source, per-packet outputs / trackers left in "
+                               "HBM, packet_spectrum + radiation_field (incl. the [L,S] j_blues download) on the device"}
+    return out
 
 
 if __name__ == "__main__":

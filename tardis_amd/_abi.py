@@ -181,13 +181,16 @@ class ResultBuffers:
 
     def __init__(self, n_packets, n_shells, n_lines, n_grid, output_nus=None, output_energies=None,
                  trackers: st.LastInteractionTrackers | None = None, vpacket_log_capacity=0,
-                 want_line_estimators=True):
+                 want_line_estimators=True, want_packet_outputs=True):
         P, S, L = int(n_packets), int(n_shells), int(n_lines)
-        self.output_nus = output_nus if output_nus is not None else np.full(P, -99.0)
-        self.output_energies = output_energies if output_energies is not None else np.full(P, -99.0)
-        for a in (self.output_nus, self.output_energies):
-            if a.dtype != np.float64 or not a.flags.c_contiguous or len(a) != P:
-                raise ValueError("output arrays must be contiguous float64 of length n_packets")
+        if want_packet_outputs:
+            self.output_nus = output_nus if output_nus is not None else np.full(P, -99.0)
+            self.output_energies = output_energies if output_energies is not None else np.full(P, -99.0)
+            for a in (self.output_nus, self.output_energies):
+                if a.dtype != np.float64 or not a.flags.c_contiguous or len(a) != P:
+                    raise ValueError("output arrays must be contiguous float64 of length n_packets")
+        else:  # the per-packet results stay on the device (NULL pointers: the library skips those copies)
+            self.output_nus = self.output_energies = None
         self.j_estimator = np.zeros(S)
         self.nu_bar_estimator = np.zeros(S)
         self.j_blue_estimator = np.zeros((L, S)) if want_line_estimators else None
@@ -200,8 +203,9 @@ class ResultBuffers:
         self.vpacket_initial_mus = np.empty(cap)
         self.vpacket_initial_rs = np.empty(cap)
         r = TardisMcResult()
-        r.output_nus = _dp(self.output_nus)
-        r.output_energies = _dp(self.output_energies)
+        if want_packet_outputs:
+            r.output_nus = _dp(self.output_nus)
+            r.output_energies = _dp(self.output_energies)
         r.j_estimator = _dp(self.j_estimator)
         r.nu_bar_estimator = _dp(self.nu_bar_estimator)
         if want_line_estimators:

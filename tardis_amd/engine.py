@@ -30,6 +30,8 @@ class Engine:
         self.n_packets = self.n_shells = self.n_lines = self.n_grid = 0
         self._vpk_log = False
         self._n_v = 0
+        self.packets_generation = 0  # bumped whenever the resident packets are replaced (lazy host views check it)
+        self.results_generation = 0  # bumped by every propagate()
 
     # -- lifetime
     def close(self):
@@ -91,11 +93,13 @@ class Engine:
         m = _abi.marshal_packets(packet_collection)
         self._check(self._L.tardis_mc_set_packets(self._h, m.ref()), "set_packets")
         self.n_packets = int(m.struct.n_packets)
+        self.packets_generation += 1
 
     def reset_estimators(self):
         self._check(self._L.tardis_mc_reset_estimators(self._h), "reset_estimators")
 
     def propagate(self):
+        self.results_generation += 1
         self._check(self._L.tardis_mc_propagate(self._h), "propagate")
 
     def synchronize(self):
@@ -120,13 +124,16 @@ class Engine:
         return int(self._L.tardis_mc_last_variant(self._h))
 
     def get_results(self, output_nus=None, output_energies=None, track_last_interaction=True,
-                    want_line_estimators=True, vpacket_log_capacity=None) -> _abi.ResultBuffers:
+                    want_line_estimators=True, vpacket_log_capacity=None, want_packet_outputs=True) -> _abi.ResultBuffers:
+        """Copy results out.  Every part is optional: per-packet outputs (`want_packet_outputs`), the last-interaction
+        trackers, the [L,S] line estimators -- whatever is not asked for stays on the device (the resident outer-iteration
+        path reads the spectrum and the radiation field through packet_spectrum() / radiation_field() instead)."""
         trackers = st.LastInteractionTrackers(self.n_packets) if track_last_interaction else None
         cap = 0
         if self._vpk_log:
             cap = int(vpacket_log_capacity if vpacket_log_capacity is not None else self.n_packets * self._n_v * 64)
         res = _abi.ResultBuffers(self.n_packets, self.n_shells, self.n_lines, self.n_grid, output_nus, output_energies,
-                                 trackers, cap, want_line_estimators)
+                                 trackers, cap, want_line_estimators, want_packet_outputs)
         rc = self._L.tardis_mc_get_results(self._h, res.ref())
         self._check(rc, "get_results", int(res.struct.first_error_packet))
         return res
@@ -145,6 +152,7 @@ class Engine:
                                                                float(temperature), st, int(max_seed_val),
                                                                l_array.ctypes.data, len(l_array)), "create_blackbody_packets")
         self.n_packets = int(count)
+        self.packets_generation += 1
 
     def get_packets(self) -> dict:
         n = self.n_packets

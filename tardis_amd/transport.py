@@ -124,6 +124,86 @@ def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, 
     return res.v_packets_energy_hist, vt, estimators_bulk, estimators_line
 
 
+class DevicePacketCollection:
+    """A PacketCollection whose arrays live in the engine: the packets were drawn by the device packet source (SURVEY 8f-1,
+    BlackBodySimpleSource.create_packets, packet_source/base.py:195-253) and propagated in place.  Same attribute names as
+    the reference's PacketCollection (packets/packet_collections.py:13-101); a host copy of an array is made the first time it
+    is read.  The engine's resident packets must still be these (a later set_packets / create_blackbody_packets on the same
+    engine invalidates the un-read arrays: reading them then raises instead of returning another run's data)."""
+
+    def __init__(self, engine: Engine, n_packets: int, radius: float, temperature: float, base_seed: int, seed_offset: int):
+        self._eng = engine
+        self._n = int(n_packets)
+        self.radius, self.temperature, self.base_seed, self.seed_offset = float(radius), float(temperature), int(base_seed), int(seed_offset)
+        self.radiation_field_luminosity = 4 * np.pi * st.SIGMA_SB * self.radius**2 * self.temperature**4  # base.py:255-270
+        self.time_of_simulation = 1 / self.radiation_field_luminosity
+        self._inputs = None
+        self._outputs = None
+        self._pgen = self._rgen = None
+
+    def _draw(self):
+        self._eng.create_blackbody_packets(self._n, self.radius, self.temperature, base_seed=self.base_seed, seed_offset=self.seed_offset)
+        self._pgen = self._eng.packets_generation
+        self._inputs = self._outputs = None
+
+    def _mark_propagated(self):
+        self._rgen = self._eng.results_generation
+        self._outputs = None
+
+    def _fresh(self, results: bool):
+        if self._pgen != self._eng.packets_generation or (results and self._rgen != self._eng.results_generation):
+            raise RuntimeError("the engine's resident packets / results are no longer this collection's (it ran something else since)")
+
+    def _in(self, name):
+        if self._inputs is None:
+            self._fresh(False)
+            self._inputs = self._eng.get_packets()
+        return self._inputs[name]
+
+    def _out(self, k):
+        if self._outputs is None:
+            self._fresh(True)
+            r = self._eng.get_results(track_last_interaction=False, want_line_estimators=False)
+            self._outputs = (r.output_nus, r.output_energies)
+        return self._outputs[k]
+
+    number_of_packets = property(lambda self: self._n)
+    initial_radii = property(lambda self: self._in("initial_radii"))
+    initial_nus = property(lambda self: self._in("initial_nus"))
+    initial_mus = property(lambda self: self._in("initial_mus"))
+    initial_energies = property(lambda self: self._in("initial_energies"))
+    packet_seeds = property(lambda self: self._in("packet_seeds"))
+    output_nus = property(lambda self: self._out(0))
+    output_energies = property(lambda self: self._out(1))
+
+
+class _DeviceEstimators:
+    """EstimatorsLine / the last-interaction trackers of a resident run: fetched from the engine on first access."""
+
+    def __init__(self, engine: Engine):
+        self._eng, self._rgen, self._line, self._trk = engine, engine.results_generation, None, None
+
+    def _fresh(self):
+        if self._rgen != self._eng.results_generation:
+            raise RuntimeError("the engine has propagated again since: these estimators are gone")
+
+    def _lines(self):
+        if self._line is None:
+            self._fresh()
+            r = self._eng.get_results(track_last_interaction=False, want_packet_outputs=False)
+            self._line = st.EstimatorsLine(r.j_blue_estimator, r.edotlu_estimator)
+        return self._line
+
+    mean_intensity_blueward = property(lambda self: self._lines().mean_intensity_blueward)
+    energy_deposition_line_rate = property(lambda self: self._lines().energy_deposition_line_rate)
+
+    def trackers(self):
+        if self._trk is None:
+            self._fresh()
+            self._trk = self._eng.get_results(track_last_interaction=True, want_line_estimators=False, want_packet_outputs=False).trackers
+        return self._trk
+
+
 class MonteCarloTransportState:
     """Result holder with the reference's property names (montecarlo_transport_state.py:15-317), unit-less."""
 
@@ -135,10 +215,44 @@ class MonteCarloTransportState:
         self.estimators_bulk = None
         self.estimators_line = None
         self.vpacket_tracker = None
-        self.tracker_last_interaction = None
+        self._tracker_last_interaction = None
         self.tracker_full_df = None
         self.enable_full_relativity = False
         self.virt_logging = False
+        self._engine = None           # set by a resident run: the reductions below then happen on the device
+        self._device_estimators = None
+
+    @property
+    def tracker_last_interaction(self):
+        if self._tracker_last_interaction is None and self._device_estimators is not None:
+            self._tracker_last_interaction = self._device_estimators.trackers()
+        return self._tracker_last_interaction
+
+    @tracker_last_interaction.setter
+    def tracker_last_interaction(self, value):
+        self._tracker_last_interaction = value
+
+    def packet_spectrum(self, spectrum_frequency_grid, luminosity_nu_start=0.0, luminosity_nu_end=float("inf")):
+        """montecarlo_emitted / reabsorbed_luminosity histograms over the spectrum grid and the filtered luminosity sums
+        (spectrum/base.py:140-159, spectrum/luminosity.py:5-30): on the device after a resident run, on the host otherwise."""
+        if self._engine is not None:
+            self.packet_collection._fresh(True)
+            return self._engine.packet_spectrum(self.time_of_simulation, luminosity_nu_start, luminosity_nu_end)
+        from . import spectrum
+        nus, en, t = self.output_nu, self.output_energy, self.time_of_simulation
+        win = (nus >= luminosity_nu_start) & (nus < luminosity_nu_end)
+        lum = en / t
+        return {"montecarlo_emitted_luminosity": spectrum.emitted_luminosity_histogram(nus, en, t, spectrum_frequency_grid),
+                "montecarlo_reabsorbed_luminosity": spectrum.reabsorbed_luminosity_histogram(nus, en, t, spectrum_frequency_grid),
+                "emitted_luminosity": float(np.sum(lum[win & (en >= 0)])), "reabsorbed_luminosity": float(-np.sum(lum[win & (en < 0)]))}
+
+    def radiation_field(self, volume, w_epsilon=1e-10, detailed_optical_window=False, want_j_blues=True):
+        """MCRadiationFieldPropertiesSolver.solve (estimators/mc_rad_field_solver.py:37-144) on the engine's resident (after
+        an N-GPU step: all-reduced) estimators.  Only after a resident run."""
+        if self._engine is None:
+            raise RuntimeError("radiation_field() needs a resident run (MCTransportSolverHIP(..., resident=True))")
+        self._device_estimators._fresh()
+        return self._engine.radiation_field(self.time_of_simulation, volume, w_epsilon, detailed_optical_window, want_j_blues)
 
     output_nu = property(lambda self: self.packet_collection.output_nus)
     output_energy = property(lambda self: self.packet_collection.output_energies)
@@ -184,25 +298,51 @@ class MonteCarloTransportState:
 
 
 class MCTransportSolverHIP:
-    """GPU counterpart of MCTransportSolverClassic (modes/classic/solver.py:46-273), plain-array inputs."""
+    """GPU counterpart of MCTransportSolverClassic (modes/classic/solver.py:46-273), plain-array inputs.
+
+    ``resident=True`` is the outer-iteration form (Simulation.iterate, simulation/base.py:419-490: create packets -> run ->
+    radiation field + luminosities -> plasma): everything the plasma step does not need stays in HBM.  Packets come from the
+    device packet source when ``initialize_transport_state`` is given ``n_packets`` instead of a packet collection; the
+    opacity tables are re-uploaded only when the opacity object changed (TARDIS builds a new one per iteration; pass
+    ``reuse_opacity=False`` if yours is mutated in place); per-packet outputs, trackers and the [L,S] line estimators are
+    fetched on first access of the respective ``transport_state`` attribute; ``transport_state.packet_spectrum`` and
+    ``.radiation_field`` reduce on the device.  Values are those of the non-resident path (tests/test_boundary_gpu.py)."""
 
     def __init__(self, spectrum_frequency_grid, montecarlo_configuration=None, line_interaction_type="macroatom",
-                 enable_full_relativity=False, device_id=None, nthreads=1):
+                 enable_full_relativity=False, device_id=None, nthreads=1, resident=False, reuse_opacity=True,
+                 enable_last_interaction_tracking=True, engine: Engine | None = None):
         self.spectrum_frequency_grid = np.ascontiguousarray(spectrum_frequency_grid, dtype=np.float64)
         self.montecarlo_configuration = montecarlo_configuration or st.MonteCarloConfiguration()
         self.line_interaction_type = line_interaction_type
         self.enable_full_relativity = enable_full_relativity
         self.nthreads = nthreads  # accepted for API compatibility; the GPU engine ignores it
         self.device_id = device_id
+        self.resident = bool(resident)
+        self.reuse_opacity = bool(reuse_opacity)
+        self.enable_last_interaction_tracking = bool(enable_last_interaction_tracking)
         self.transport_state = None
+        self._engine = engine          # (default: the process-wide engine of the device)
+        self._resident_opacity = None  # (engine, opacity object) whose tables are in HBM
+
+    def _eng(self) -> Engine:
+        return self._engine if self._engine is not None else get_engine(self.device_id)
 
     def initialize_transport_state(self, packet_collection, geometry, opacity_state, time_explosion,
-                                   no_of_virtual_packets=0):
+                                   no_of_virtual_packets=0, *, n_packets=None, iteration=0, temperature_inner=None,
+                                   base_seed=None):
         cfg = self.montecarlo_configuration
         cfg.LINE_INTERACTION_TYPE = st.LINE_INTERACTION_TYPES[self.line_interaction_type]
         cfg.NUMBER_OF_VPACKETS = no_of_virtual_packets
         cfg.TEMPORARY_V_PACKET_BINS = no_of_virtual_packets
         cfg.ENABLE_FULL_RELATIVITY = self.enable_full_relativity
+        if packet_collection is None:
+            # device packet source: BlackBodySimpleSource(radius = r_inner[0], temperature = T_inner, base_seed).create_packets(
+            # n_packets, seed_offset = iteration) -- simulation/base.py:419-433
+            if not self.resident or n_packets is None or temperature_inner is None:
+                raise ValueError("the device packet source needs resident=True, n_packets and temperature_inner")
+            seed = cfg.MONTECARLO_SEED if base_seed is None else base_seed
+            packet_collection = DevicePacketCollection(self._eng(), n_packets, float(np.asarray(geometry.r_inner)[0]),
+                                                       temperature_inner, seed, iteration)
         ts = MonteCarloTransportState(packet_collection, geometry, opacity_state, time_explosion)
         ts.enable_full_relativity = cfg.ENABLE_FULL_RELATIVITY
         return ts
@@ -211,6 +351,8 @@ class MCTransportSolverHIP:
         return self.run_classic(transport_state, show_progress_bars)
 
     def run_classic(self, transport_state, show_progress_bars=False):
+        if self.resident:
+            return self._run_resident(transport_state)
         self.transport_state = transport_state
         cfg = self.montecarlo_configuration
         n = len(transport_state.packet_collection.initial_nus)
@@ -218,7 +360,7 @@ class MCTransportSolverHIP:
         hist, vtracker, est_bulk, est_line = montecarlo_transport_with_vpackets(
             transport_state.packet_collection, transport_state.geometry_state_numba, float(transport_state.time_explosion),
             transport_state.opacity_state_numba, cfg, self.spectrum_frequency_grid, trackers, cfg.NUMBER_OF_VPACKETS,
-            show_progress_bars, None, engine=get_engine(self.device_id))
+            show_progress_bars, None, engine=self._eng())
         transport_state.estimators_bulk = est_bulk
         transport_state.estimators_line = est_line
         if cfg.ENABLE_VPACKET_TRACKING and cfg.NUMBER_OF_VPACKETS > 0:
@@ -226,3 +368,43 @@ class MCTransportSolverHIP:
         transport_state.tracker_last_interaction = trackers
         transport_state.virt_logging = cfg.ENABLE_VPACKET_TRACKING
         return hist
+
+    def _run_resident(self, ts):
+        self.transport_state = ts
+        cfg = self.montecarlo_configuration
+        if cfg.ENABLE_VPACKET_TRACKING and cfg.NUMBER_OF_VPACKETS > 0:
+            raise NotImplementedError("the consolidated v-packet log is a per-v-packet host result: use resident=False with it")
+        eng = self._eng()
+        eng.set_geometry(ts.geometry_state_numba, float(ts.time_explosion))
+        op = ts.opacity_state_numba
+        if not (self.reuse_opacity and self._resident_opacity is not None and self._resident_opacity[0] is eng
+                and self._resident_opacity[1] is op):
+            eng.set_opacity(op)
+            self._resident_opacity = (eng, op)
+        eng.set_config(cfg, self.spectrum_frequency_grid, cfg.NUMBER_OF_VPACKETS)
+        eng.set_option("track_last_interaction", int(self.enable_last_interaction_tracking))
+        pc = ts.packet_collection
+        device_packets = isinstance(pc, DevicePacketCollection)
+        if device_packets:
+            pc._draw()
+        else:
+            eng.set_packets(pc)
+        eng.reset_estimators()
+        eng.propagate()
+        eng.synchronize()
+        res = eng.get_results(track_last_interaction=False, want_line_estimators=False, want_packet_outputs=False)  # small arrays + error check
+        if device_packets:
+            pc._mark_propagated()
+        else:  # host packets: the reference's in-place outputs
+            r = eng.get_results(pc.output_nus, pc.output_energies, track_last_interaction=False, want_line_estimators=False)
+            if r.output_nus is not pc.output_nus:
+                pc.output_nus[:] = r.output_nus; pc.output_energies[:] = r.output_energies
+        ts._engine = eng if device_packets else None
+        ts._device_estimators = _DeviceEstimators(eng)
+        ts.estimators_bulk = st.EstimatorsBulk(res.j_estimator, res.nu_bar_estimator)
+        ts.estimators_line = ts._device_estimators
+        ts._tracker_last_interaction = None if self.enable_last_interaction_tracking else st.LastInteractionTrackers(0)
+        ts.virt_logging = False
+        montecarlo_transport_with_vpackets.last_counters = res.counters
+        montecarlo_transport_with_vpackets.last_kernel_ms = eng.last_propagate_ms()
+        return res.v_packets_energy_hist

@@ -13,7 +13,7 @@ from tardis_amd import synthetic
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
                if f.endswith(".npz") and f != "libm_probe.npz"
-               and not f.startswith(("formal_", "packet_source_", "radfield_")))  # (those: test_formal_integral.py, test_next_rows_golden.py)
+               and not f.startswith(("formal_", "packet_source_", "radfield_", "legacy_packet_source_")))  # (those: test_formal_integral.py, test_next_rows_golden.py)
 
 
 def load_case(name):

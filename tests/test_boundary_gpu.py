@@ -120,3 +120,89 @@ def test_scatter_mode_with_the_reference_placeholder_tables():
                                                  prob.spectrum_frequency_grid, None, 0, False, None)
     assert_allclose(pc.output_nus, g["output_nus"], rtol=1e-13, atol=0)
     assert_allclose(pc.output_energies, g["output_energies"], rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("name", ["macroatom_nv0", "downbranch_nv0"])
+def test_resident_run_with_host_packets_holds_the_same_values(name):
+    """MCTransportSolverHIP(resident=True): results stay in HBM until read; every property the non-resident test above checks
+    has the golden's value, and the second run on the same opacity object skips the table upload."""
+    prob, g = _golden.load_case(name)
+    cfg = prob.montecarlo_configuration
+    mode = {0: "scatter", 1: "downbranch", 2: "macroatom"}[int(cfg.LINE_INTERACTION_TYPE)]
+    solver = transport.MCTransportSolverHIP(prob.spectrum_frequency_grid, cfg, line_interaction_type=mode, device_id=0, resident=True)
+    for _ in range(2):
+        ts = solver.initialize_transport_state(prob.packet_collection, prob.geometry, prob.opacity_state, prob.time_explosion)
+        hist = solver.run(ts)
+        assert_allclose(ts.output_nu, g["output_nus"], rtol=1e-13, atol=0)
+        assert_allclose(ts.output_energy, g["output_energies"], rtol=1e-13, atol=0)
+        assert_allclose(ts.j_estimator, g["j_estimator"], rtol=EST_RTOL)
+        assert_allclose(ts.nu_bar_estimator, g["nu_bar_estimator"], rtol=EST_RTOL)
+        stride = int(g["line_estimator_stride"])
+        assert_allclose(ts.j_blue_estimator[::stride], g["j_blue_estimator"], rtol=EST_RTOL)
+        assert_allclose(ts.Edotlu_estimator[::stride], g["edotlu_estimator"], rtol=EST_RTOL)
+        assert_allclose(hist, g["v_packets_energy_hist"], rtol=EST_RTOL)
+        df = ts.tracker_last_interaction_df
+        assert np.array_equal(df["event_id"].to_numpy(), g["trk_interactions_count"])
+        assert np.array_equal(df["line_emit_id"].to_numpy(), g["trk_interaction_line_emit_id"])
+        assert_allclose(df["after_nu"].to_numpy(), g["trk_after_nu"], rtol=1e-13, atol=0, equal_nan=True)
+        # host-side reductions of a host-packet run equal numpy's own
+        sp = ts.packet_spectrum(prob.spectrum_frequency_grid)
+        lum = g["output_energies"] / ts.time_of_simulation
+        assert_allclose(sp["emitted_luminosity"], lum[lum >= 0].sum(), rtol=1e-12)
+
+
+def test_resident_outer_iterations_with_the_device_packet_source():
+    """Two outer iterations the way Simulation.iterate runs them (simulation/base.py:419-490), nothing per-packet crossing PCIe:
+    packets drawn on the device (seed_offset = iteration), propagated, spectrum / luminosities and the radiation field reduced
+    on the device.  Checked against the non-resident drop-in call on the very packets the device drew."""
+    from tardis_amd import synthetic
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=5, n_packets=1, n_shells=8, n_lines=3000, line_interaction_type="macroatom")
+    cfg = prob.montecarlo_configuration
+    grid = prob.spectrum_frequency_grid
+    geo = prob.geometry
+    volume = 4.0 / 3.0 * np.pi * (geo.r_outer**3 - geo.r_inner**3)
+    n, t_inner = 30_000, 1.0e4
+    solver = transport.MCTransportSolverHIP(grid, cfg, line_interaction_type="macroatom", device_id=0, resident=True)
+    for iteration in (0, 1):
+        ts = solver.initialize_transport_state(None, geo, prob.opacity_state, prob.time_explosion, n_packets=n,
+                                               iteration=iteration, temperature_inner=t_inner)
+        solver.run(ts)
+        sp = ts.packet_spectrum(grid, luminosity_nu_start=2.0e14, luminosity_nu_end=2.0e15)
+        rf = ts.radiation_field(volume, w_epsilon=1e-10)
+        pc = ts.packet_collection
+        assert pc.number_of_packets == n
+        # the same packets through the ordinary drop-in call on a second engine
+        host = st.PacketCollection(pc.initial_radii, pc.initial_nus, pc.initial_mus, pc.initial_energies, pc.packet_seeds,
+                                   pc.radiation_field_luminosity)
+        if iteration == 1:  # iterations draw different packets (seed_offset)
+            assert not np.array_equal(pc.packet_seeds, first_seeds)
+        first_seeds = pc.packet_seeds
+        with Engine(0) as other:
+            hist, vt, eb, el = transport.montecarlo_transport_with_vpackets(host, geo, prob.time_explosion, prob.opacity_state, cfg,
+                                                                            grid, None, 0, False, None, engine=other)
+        assert np.array_equal(ts.output_nu, host.output_nus) and np.array_equal(ts.output_energy, host.output_energies)
+        assert_allclose(ts.j_estimator, eb.mean_intensity_total, rtol=EST_RTOL)
+        assert_allclose(ts.j_blue_estimator, el.mean_intensity_blueward, rtol=EST_RTOL)
+        from tardis_amd import spectrum
+        assert_allclose(sp["montecarlo_emitted_luminosity"],
+                        spectrum.emitted_luminosity_histogram(host.output_nus, host.output_energies, host.time_of_simulation, grid), rtol=1e-11)
+        lum = host.output_energies / host.time_of_simulation
+        win = (host.output_nus >= 2.0e14) & (host.output_nus < 2.0e15)
+        assert_allclose(sp["emitted_luminosity"], lum[win & (lum >= 0)].sum(), rtol=1e-11)
+        assert_allclose(sp["reabsorbed_luminosity"], -lum[win & (lum < 0)].sum(), rtol=1e-11)
+        # the radiation field against the oracle of that row on the non-resident estimators
+        from oracle import radfield
+        t_rad, w, jb = radfield.solve(eb.mean_intensity_total, eb.mean_frequency, el.mean_intensity_blueward.copy(), prob.time_explosion,
+                                      host.time_of_simulation, volume, prob.opacity_state.line_list_nu, w_epsilon=1e-10,
+                                      detailed_optical_window=False)
+        assert_allclose(rf["t_radiative"], t_rad, rtol=1e-10)
+        assert_allclose(rf["dilution_factor"], w, rtol=1e-10)
+        assert_allclose(rf["j_blues"], jb, rtol=1e-10)
+    # a stale view must not hand out another run's data
+    ts_old = ts
+    ts2 = solver.initialize_transport_state(None, geo, prob.opacity_state, prob.time_explosion, n_packets=100, iteration=2,
+                                            temperature_inner=t_inner)
+    solver.run(ts2)
+    with pytest.raises(RuntimeError):
+        ts_old.packet_spectrum(grid)
