@@ -160,6 +160,8 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
  * launches over one packet supply), "log_sets" (1: the estimator passes of an epoch run before the next
  * epoch instead of beside it), "chunk_packets" (packets per launch of the group kernel), "waves_per_simd", "group_size",
  * "blocks_per_cu", "estimator_copies" (1..8 private j_blue/Edotlu copies),
+ * "vpacket_screening" (v-packets whose Russian roulette is decided from prefix sums of tau instead of a line-by-line trace,
+ * csrc/tau_prefix.hpp: -1 automatic -- on where a shell crossing passes many lines --, 0 off, 1 on),
  * "debug_flags" (profiling experiments / cross-checks only: 1 skips the j_blue/Edotlu updates, 2 the J/nu_bar updates, 128
  * walks the macro atom by a per-lane search in the fp64 running sums, 8192 by the cooperative group scan; tests: 16384 counts
  * the jumps out of blocks longer than one window of the compact walk tables into counters[7], 32768 the jumps decided by the

@@ -136,6 +136,9 @@ struct GroupArgs {
     const int *bucket_first;
     int bucket_shift, bucket_n;
     long long bucket_kmin;
+    // v-packet screening (tau_prefix.hpp): prefix sums of tau along every shell's row, [S][L + 1], and the row totals; null when
+    // the screening is off (survival probability > 0, a negative optical depth, debug flag)
+    const double *tau_pfx, *tau_rowsum;
 };
 
 struct Packet {

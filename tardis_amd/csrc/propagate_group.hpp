@@ -529,6 +529,129 @@ __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &r
     return 0;
 }
 
+// The same trace with the optical depths of a shell crossing taken from the prefix sums of the row (tau_prefix.hpp): decides the
+// Russian roulette -- and with the default survival probability 0 the whole v-packet -- without reading the lines.
+// Returns 1: the v-packet is dropped (energy 0; dr.used and vvisits as the line-by-line trace would leave them);
+//         0: not decided here (it leaves the grid alive, or comes within the error margin of the threshold, or drew exactly 0.0):
+//            the caller traces it line by line from the start; < 0: error (the reference raises).
+// A v-packet never changes direction, so its whole path -- radii, angles, boundary distances, comoving frequencies at the
+// boundaries -- is arithmetic on the geometry in LDS; only the line indices need memory.  One round trip per shell crossing: while
+// the four-line window around the frequency-bucket guess of crossing k is in flight (frequencies, the prefix sums of this
+// shell's row and of the next shell's row at the same indices: the stopping line of k is the start line of k + 1), so is the
+// bucket look-up of crossing k + 1, whose geometry is computed ahead.
+template <bool FULL, int G>
+__device__ __forceinline__ int vp_screen(const GroupArgs &P, const GroupRng<G> &rng, VpDraws &dr, double r, double mu, double nu,
+                                         int shell, int next_line, unsigned &vvisits, const double *geo)
+{
+    const int L = P.n_lines, S = P.n_shells;
+    const double t = P.t_exp;
+    typedef double dbl2 __attribute__((ext_vector_type(2), aligned(8)));
+    struct Crossing { double d_boundary, comov_nu, tau_cont; int delta, bucket_e; };
+    auto geometry = [&](double rr, double mm, int sh, Crossing &c) {
+        distance_boundary(rr, mm, geo[sh], geo[S + sh], c.d_boundary, c.delta);
+        const double dop = doppler_factor<FULL>(rr / t, mm);
+        c.comov_nu = nu * dop;
+        double chi_cont = geo[2 * S + sh] * P.sigma_thomson;
+        if (FULL) chi_cont *= dop;
+        c.tau_cont = chi_cont * c.d_boundary;
+        const double nu_thr = c.comov_nu - c.d_boundary * P.rcp_tc * nu;
+        long long kk = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
+        kk = kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
+        c.bucket_e = P.bucket_first[kk];
+    };
+    double tau = 0.0, margin = 0.0;
+    unsigned visits = 0;
+    Crossing cur;
+    geometry(r, mu, shell, cur);
+    double nl_start = P.nu_line[(unsigned)min(next_line, L - 1)];
+    double p_start = P.tau_pfx[(size_t)shell * (size_t)(L + 1) + (unsigned)min(next_line, L)];
+    for (;;) {
+        const int start = next_line;
+        // where the v-packet is after this crossing, and the geometry (and bucket look-up) of the next one
+        const double new_r = sqrt(r * r + cur.d_boundary * cur.d_boundary + 2.0 * r * cur.d_boundary * mu);
+        const double new_mu = (mu * r + cur.d_boundary) / new_r;
+        int status = ST_IN_PROCESS, nshell = shell;
+        cross_shell(nshell, status, cur.delta, S);
+        Crossing nxt = cur;
+        const bool leaves = status == ST_EMITTED;
+        if (!leaves) geometry(new_r, new_mu, nshell, nxt);
+        const double *__restrict__ prow = P.tau_pfx + (size_t)shell * (size_t)(L + 1);
+        const double *__restrict__ nrow = P.tau_pfx + (size_t)(leaves ? shell : nshell) * (size_t)(L + 1);
+        double seg = 0.0, p_next = nrow[(unsigned)min(start, L)], nl_next = nl_start;
+        int n_sum = 0;
+        if (start < L) {
+            double d_line;
+            if (!distance_line<FULL>(nu, r, mu, cur.comov_nu, start == L - 1, nl_start, t, d_line)) return ERR_MONTECARLO;
+            int e = start;
+            if (!(cur.d_boundary <= d_line)) {
+                e = max(cur.bucket_e, start + 1);
+                if (e > L - 1) e = L - 1;
+                auto stops_at_nu = [&](int k, double nl) -> bool {
+                    double d;
+                    (void)distance_line<FULL>(nu, r, mu, cur.comov_nu, k == L - 1, nl, t, d);
+                    return cur.d_boundary <= d;
+                };
+                auto stops_at = [&](int k) -> bool { return stops_at_nu(k, P.nu_line[(unsigned)k]); };
+                const int w0 = max(e - 1, start + 1);
+                const dbl2 wa = *reinterpret_cast<const dbl2 *>(P.nu_line + (unsigned)w0), wb = *reinterpret_cast<const dbl2 *>(P.nu_line + (unsigned)w0 + 2);
+                const dbl2 pa = *reinterpret_cast<const dbl2 *>(prow + (unsigned)w0), pb = *reinterpret_cast<const dbl2 *>(prow + (unsigned)w0 + 2);
+                const dbl2 qa = *reinterpret_cast<const dbl2 *>(nrow + (unsigned)w0), qb = *reinterpret_cast<const dbl2 *>(nrow + (unsigned)w0 + 2);
+                const double wn[4] = {wa.x, wa.y, wb.x, wb.y}, wp[4] = {pa.x, pa.y, pb.x, pb.y}, wq[4] = {qa.x, qa.y, qb.x, qb.y};
+                bool sw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sw[i] = stops_at_nu(min(w0 + i, L - 1), wn[i]);
+                int hit = -1;  // window slot of the stopping line, when the window pins it
+                if (sw[0]) { if (w0 == start + 1) hit = 0; }
+                else if (sw[1]) hit = 1;
+                else if (sw[2]) hit = 2;
+                else if (sw[3]) hit = 3;
+                if (hit >= 0 && w0 + hit <= L - 1) {
+                    e = w0 + hit;
+                    double pe = wp[0], qe = wq[0], ne = wn[0];
+#pragma unroll
+                    for (int i = 1; i < 4; ++i) if (hit == i) { pe = wp[i]; qe = wq[i]; ne = wn[i]; }
+                    seg = pe - p_start; p_next = qe; nl_next = ne;
+                } else {  // the bucket guess was further off (or the window ran past the list): the reference's walk
+                    e = sw[0] ? w0 : min(w0 + 3, L - 1);
+                    bool stops;
+                    for (;;) {
+                        if (stops_at(e) || e == L - 1) break;
+                        ++e;
+                    }
+                    stops = stops_at(e);
+                    while (e > start + 1) {
+                        if (!stops_at(e - 1)) break;
+                        --e;
+                        stops = true;
+                    }
+                    if (!stops) e = L;
+                    seg = prow[(unsigned)min(e, L)] - p_start;
+                    p_next = nrow[(unsigned)min(e, L)];
+                    nl_next = P.nu_line[(unsigned)min(e, L - 1)];
+                }
+            }
+            n_sum = min(e, L) - start;
+            visits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
+            next_line = e;
+        }
+        const double tau_shell = cur.tau_cont + seg;
+        tau += tau_shell;
+        margin += 2.3e-16 * (geo[3 * S + shell] + (double)(n_sum + 4) * tau_shell + 2.0 * tau);
+        if (tau - 2.0 * margin > P.tau_russian) {  // the reference's `tau_trace_combined > tau_russian` is certainly true
+            double ev = 0.0;
+            if (dr.used < dr.limit) ev = rng.peek(dr.first + dr.used); else dr.overflow = true;
+            dr.used++;
+            if (!(ev > P.survival_probability)) { dr.used = 0; dr.overflow = false; return 0; }  // (a draw of exactly 0.0)
+            vvisits += visits;
+            return 1;
+        }
+        if (!(tau + 2.0 * margin < P.tau_russian)) return 0;  // too close to call
+        if (leaves) return 0;                                 // leaves the grid alive: its energy needs the reference's own sum
+        r = new_r; mu = new_mu; shell = nshell;
+        cur = nxt; p_start = p_next; nl_start = nl_next;
+    }
+}
+
 template <bool FULL, int G>
 __device__ __forceinline__ int volley_group(const GroupArgs &P, const Packet &p, GroupRng<G> &rng, const int j, long long packet_index,
                                             int &vseq, unsigned &pred_bits, unsigned &vvisits, unsigned &vcount, unsigned long long &vtraced,
@@ -599,9 +722,20 @@ __device__ __forceinline__ int volley_group(const GroupArgs &P, const Packet &p,
             const double ratio = r_dop / v_dop;
             v_nu = p.nu * ratio;
             v_energy = p.energy * weight * ratio;
-            double tau_v;
-            err = vp_trace<FULL, G>(P, rng, dr, p.r, v_mu, v_nu, v_energy, p.shell, p.next_line_id, tau_v, my_visits, geo);
-            if (!err) v_energy *= mcm::exp(-tau_v);
+            int screened = 0;
+            // (only v-packets expected to be dropped: bit i of the roulette predictor -- a v-packet that leaves the grid alive
+            // needs the line-by-line trace anyway, and the screening would be a second trace on top of it)
+            if (P.tau_pfx && pred_self) screened = vp_screen<FULL, G>(P, rng, dr, p.r, v_mu, v_nu, p.shell, p.next_line_id, my_visits, geo);
+            if (screened > 0) {
+                v_energy = 0.0;  // dropped by the roulette (virtual_packet.py:221-226)
+                if (P.debug_flags & 67108864) vtraced += 1ull << 40;  // tests: v-packets decided on the prefix sums -> counters[7] >> 40
+            }
+            else if (screened < 0) err = screened;
+            else {
+                double tau_v;
+                err = vp_trace<FULL, G>(P, rng, dr, p.r, v_mu, v_nu, v_energy, p.shell, p.next_line_id, tau_v, my_visits, geo);
+                if (!err) v_energy *= mcm::exp(-tau_v);
+            }
             if (dr.overflow) err = ERR_UNSUPPORTED;
         }
         // the first lane whose draw consumption differs from the prediction (or that failed) ends the validity of the round:
@@ -618,7 +752,7 @@ __device__ __forceinline__ int volley_group(const GroupArgs &P, const Packet &p,
             ++vcount;
             vvisits += my_visits;
             // add_vpacket_collection_to_histogram (modes/montecarlo_transport.py:166-195)
-            if (!(v_nu < P.grid0 || v_nu > P.grid_last)) {
+            if (!(v_nu < P.grid0 || v_nu > P.grid_last) && v_energy != 0.0) {  // (a dropped v-packet adds 0.0: the bin keeps its bits)
                 long long idx = (long long)floor((v_nu - P.grid0) / P.delta_nu);
                 atomic_add_f64(&P.vhist[idx], v_energy);
             }
@@ -649,7 +783,7 @@ __device__ __forceinline__ int volley_group(const GroupArgs &P, const Packet &p,
 template <int G, int BLOCK>
 __host__ __device__ constexpr size_t group_kernel_lds_bytes(int n_shells)
 {
-    return (size_t)(BLOCK / G) * sizeof(LdsTracker) + 5 * (size_t)n_shells * sizeof(double);  // J, nu_bar; r_inner, r_outer, n_e for the v-packet traces
+    return (size_t)(BLOCK / G) * sizeof(LdsTracker) + 6 * (size_t)n_shells * sizeof(double);  // J, nu_bar; r_inner, r_outer, n_e, tau row sums for the v-packet traces
 }
 
 template <bool FULL, bool TRACK, int G, int BLOCK, int OCC, bool VPK>
@@ -666,6 +800,7 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
     if (VPK)
         for (int s = threadIdx.x; s < P.n_shells; s += BLOCK) {
             lds_geo[s] = P.r_inner[s]; lds_geo[P.n_shells + s] = P.r_outer[s]; lds_geo[2 * P.n_shells + s] = P.n_e[s];
+            lds_geo[3 * P.n_shells + s] = P.tau_rowsum ? P.tau_rowsum[s] : 0.0;
         }
     __syncthreads();
 

@@ -95,7 +95,7 @@ template <bool FULL, bool VPK, bool LS = false>
 __host__ __device__ constexpr size_t wave_kernel_lds_bytes(int n_shells)
 {
     return (LS ? WAVE_SHARED_LS_BYTES : sizeof(WaveShared)) + (FULL ? sizeof(WaveSharedFull) : 0) + (size_t)(VPK ? WV_RING_VPK : WV_RING) * 64 * sizeof(double) +
-           (size_t)5 * (size_t)n_shells * sizeof(double);  // J, nu_bar, r_inner, r_outer, n_e
+           (size_t)(VPK ? 6 : 5) * (size_t)n_shells * sizeof(double);  // J, nu_bar, r_inner, r_outer, n_e (+ the tau row sums of the v-packet screening)
 }
 
 // result of one (possibly speculative) v-packet trace, handed from the worker lane to the owner lane through global scratch
@@ -579,6 +579,116 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
     return status == ST_EMITTED ? 1 : 0;
 }
 
+// One shell crossing of the SCREENING trace (tau_prefix.hpp): the crossing's optical depth from the prefix sums of the shell's row
+// instead of its lines -- two round trips (line at `start`, prefix at `start`, frequency bucket of the boundary | four-line window
+// of frequencies and prefix sums around the bucket guess).  v.tau / margin accumulate the approximate depth and its rigorous error
+// bound.  Returns 1: the v-packet is certainly dropped by the roulette (one draw consumed, energy 0); 0: go on; 2: undecided here
+// (leaves the grid alive, within the margin of the threshold, or drew exactly 0.0): the caller restarts it with vp_shell_step.
+template <bool FULL, typename Draw>
+__device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, int &draws_left, VpState &v, double &margin, double rcp_nu, bool fast_nu,
+                                              const double *__restrict__ geo /* LDS: r_inner | r_outer | n_e | tau row sums */, unsigned &vvisits)
+{
+    const int L = P.n_lines, S = P.n_shells;
+    const double t = P.t_exp;
+    int status = ST_IN_PROCESS;
+    const int start = v.next_line;
+    const int start_c = min(start, L - 1);
+    const double *__restrict__ prow = P.tau_pfx + (size_t)v.shell * (size_t)(L + 1);
+    const double nl_start = P.nu_line[(unsigned)start_c];
+    const double p_start = prow[(unsigned)min(start, L)];
+    double d_boundary;
+    int delta;
+    distance_boundary(v.r, v.mu, geo[v.shell], geo[S + v.shell], d_boundary, delta);
+    const double velocity = v.r / t;
+    const double dop = doppler_factor<FULL>(velocity, v.mu);
+    const double comov_nu = v.nu * dop;
+    double chi_cont = geo[2 * S + v.shell] * P.sigma_thomson;
+    if (FULL) chi_cont *= dop;
+    const double tau_cont = chi_cont * d_boundary;
+    const double nu_thr = comov_nu - d_boundary * P.rcp_tc * v.nu;
+    long long kk_b = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
+    kk_b = kk_b < 0 ? 0 : (kk_b >= P.bucket_n ? P.bucket_n - 1 : kk_b);
+    const int bucket_e = P.bucket_first[kk_b];
+    auto d_line_of = [&](int k, double nl) -> double {
+        if (FULL) {
+            double d;
+            distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, k == L - 1, nl, t, d);
+            return d;
+        }
+        const double nu_diff = comov_nu - nl;
+        const double q = (fast_nu && mid_range(nu_diff)) ? exact_div<true>(nu_diff, v.nu, rcp_nu) : nu_diff / v.nu;
+        const double d = (fabs(q) < CLOSE_LINE_THRESHOLD) ? 0.0 : q * C_LIGHT * t;
+        return (k == L - 1) ? MISS_DISTANCE : d;
+    };
+    double seg = 0.0;
+    int n_sum = 0;
+    if (start < L) {
+        double d_line;
+        if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, start == L - 1, nl_start, t, d_line)) return ERR_MONTECARLO;
+        int e = start;
+        if (!(d_boundary <= d_line)) {
+            e = max(bucket_e, start + 1);
+            if (e > L - 1) e = L - 1;
+            const int w0 = max(e - 1, start + 1);
+            typedef double dbl2 __attribute__((ext_vector_type(2), aligned(8)));
+            const dbl2 wa = *reinterpret_cast<const dbl2 *>(P.nu_line + (unsigned)w0), wb = *reinterpret_cast<const dbl2 *>(P.nu_line + (unsigned)w0 + 2);
+            const dbl2 pa = *reinterpret_cast<const dbl2 *>(prow + (unsigned)w0), pb = *reinterpret_cast<const dbl2 *>(prow + (unsigned)w0 + 2);
+            const double wn[4] = {wa.x, wa.y, wb.x, wb.y}, wp[4] = {pa.x, pa.y, pb.x, pb.y};
+            bool sw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw[i] = d_boundary <= d_line_of(min(w0 + i, L - 1), wn[i]);
+            int hit = -1;
+            if (sw[0]) { if (w0 == start + 1) hit = 0; }
+            else if (sw[1]) hit = 1;
+            else if (sw[2]) hit = 2;
+            else if (sw[3]) hit = 3;
+            if (hit >= 0 && w0 + hit <= L - 1) {
+                e = w0 + hit;
+                double pe = wp[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i) if (hit == i) pe = wp[i];
+                seg = pe - p_start;
+            } else {  // the bucket guess was further off: the reference's walk, forward then backward
+                e = sw[0] ? w0 : min(w0 + 3, L - 1);
+                for (;;) {
+                    d_line = d_line_of(e, P.nu_line[(unsigned)e]);
+                    if (d_boundary <= d_line || e == L - 1) break;
+                    ++e;
+                }
+                bool stops = d_boundary <= d_line;
+                while (e > start + 1) {
+                    if (!(d_boundary <= d_line_of(e - 1, P.nu_line[(unsigned)(e - 1)]))) break;
+                    --e;
+                    stops = true;
+                }
+                if (!stops) e = L;
+                seg = prow[(unsigned)min(e, L)] - p_start;
+            }
+        }
+        n_sum = min(e, L) - start;
+        vvisits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
+        v.next_line = e;
+    }
+    const double tau_shell = tau_cont + seg;
+    v.tau += tau_shell;
+    margin += 2.3e-16 * (geo[3 * S + v.shell] + (double)(n_sum + 4) * tau_shell + 2.0 * v.tau);
+    cross_shell(v.shell, status, delta, S);
+    if (v.tau - 2.0 * margin > P.tau_russian) {  // the reference's `tau_trace_combined > tau_russian` is certainly true
+        if (draws_left <= 0) return ERR_UNSUPPORTED;
+        --draws_left;
+        const double ev = draw();
+        if (!(ev > P.survival_probability)) return 2;  // (a draw of exactly 0.0)
+        v.energy = 0.0;
+        return 1;
+    }
+    if (!(v.tau + 2.0 * margin < P.tau_russian)) return 2;  // too close to call
+    if (status == ST_EMITTED) return 2;                     // leaves the grid alive: its energy needs the reference's own sum
+    const double new_r = sqrt(v.r * v.r + d_boundary * d_boundary + 2.0 * v.r * d_boundary * v.mu);
+    v.mu = (v.mu * v.r + d_boundary) / new_r;
+    v.r = new_r;
+    return 0;
+}
+
 template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3 : 4, VPK ? 3 : 4))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
@@ -593,6 +703,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     double *lds_geo = lds_nubar + H.n_shells;  // r_inner | r_outer | n_e
     for (int s = threadIdx.x; s < H.n_shells; s += 64) {
         lds_geo[s] = W->P.r_inner[s]; lds_geo[H.n_shells + s] = W->P.r_outer[s]; lds_geo[2 * H.n_shells + s] = W->P.n_e[s];
+        if (VPK) lds_geo[3 * H.n_shells + s] = W->P.tau_rowsum ? W->P.tau_rowsum[s] : 0.0;
     }
     const int lane = threadIdx.x;  // one wave per workgroup
     {   // (volley queue: a wave keeps its partial sums from launch to launch and adds them to the estimators when it is done)
@@ -1281,7 +1392,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             ++vcount;
                             vvisits_total += (unsigned)r.visits;
                             // add_vpacket_collection_to_histogram (modes/montecarlo_transport.py:166-195)
-                            if (!(r.nu < P.grid0 || r.nu > P.grid_last)) {
+                            if (!(r.nu < P.grid0 || r.nu > P.grid_last) && r.energy != 0.0) {  // (a dropped v-packet adds 0.0: the bin keeps its bits)
                                 const long long idx = (long long)floor((r.nu - P.grid0) / P.delta_nu);
                                 atomic_add_f64(&P.vhist[idx], r.energy);
                             }
@@ -1408,6 +1519,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 double v_rcp_nu = 0.0;
                 bool v_fast = false;
                 vs.r = vs.mu = vs.nu = vs.energy = vs.tau = vs.mu0 = 0.0; vs.shell = 0; vs.next_line = 0;
+                // screening (tau_prefix.hpp): an item predicted to be dropped by the roulette is first traced on the prefix sums; if
+                // that does not decide it, it starts again line by line from its launch state (v0_*)
+                bool screening = false;
+                double v_margin = 0.0, v0_r = 0.0, v0_energy = 0.0;
+                int v0_shell = 0, v0_line = 0;
                 for (;;) {
                     const unsigned long long free_l = __ballot(!tracing);
                     const int n_take = min(__popcll(free_l), n_items - next);
@@ -1449,6 +1565,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             vs.tau = 0.0; vs.shell = f_shell; vs.next_line = f_line;
                             my_visits = 0;
                             tracing = true;
+                            screening = P.tau_pfx != nullptr && ((f_pred >> i) & 1u) != 0u;
+                            v_margin = 0.0; v0_r = f_r; v0_energy = vs.energy; v0_shell = f_shell; v0_line = f_line;
                         }
                     }
                     if (tracing) {
@@ -1458,7 +1576,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             return d;
                         };
                         int draws_left = w_avail - (w_q + w_used);
-                        const int st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, v_rcp_nu, v_fast, lds_geo, my_visits);
+                        int st;
+                        if (screening) {
+                            st = vp_screen_step<FULL>(P, wdraw, draws_left, vs, v_margin, v_rcp_nu, v_fast, lds_geo, my_visits);
+                            if (st == 1 && (P.debug_flags & 67108864)) vtraced_total += 1ull << 40;  // tests: decided on the prefix sums -> counters[7] >> 40
+                            if (st == 2) {  // not decided on the prefix sums: again, line by line
+                                vs.r = v0_r; vs.mu = vs.mu0; vs.energy = v0_energy; vs.tau = 0.0; vs.shell = v0_shell; vs.next_line = v0_line;
+                                my_visits = 0; w_used = 0; screening = false; st = 0;
+                            }
+                        } else
+                            st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, v_rcp_nu, v_fast, lds_geo, my_visits);
                         if (st != 0) {
                             VpResult r;
                             r.nu = vs.nu; r.energy = st == 1 ? vs.energy * mcm::exp(-vs.tau) : 0.0; r.mu0 = vs.mu0;

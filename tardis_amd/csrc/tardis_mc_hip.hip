@@ -24,6 +24,7 @@
 #include "propagate_wave.hpp"
 #include "packet_source.hpp"
 #include "formal_integral.hpp"
+#include "tau_prefix.hpp"
 
 namespace {
 
@@ -99,6 +100,8 @@ struct TardisMcContext {
     int n_lines = 0, n_trans = 0, n_levels = 0;
     DevBuf nu_line, tau_t, n_e, prob_t, cum_t, trans_nu, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec, bucket_first;
     DevBuf cum16, rec16, quad_info, line_block_c;  // compact walk tables (walk_tables.hpp)
+    DevBuf tau_pfx, tau_rowsum;                    // v-packet screening tables (tau_prefix.hpp), built at the first v-packet call after set_opacity
+    bool pfx_valid = false, pfx_negative = false;
     unsigned cum16_stride = 0;
     bool have_walk_tables = false;
     int bucket_shift = 0, bucket_n = 0;
@@ -133,6 +136,7 @@ struct TardisMcContext {
     int ls_min_active = 8, ls_max_steps = 1 << 30;  // lane sweeps: when to leave the sweep phase (propagate_wave.hpp)
     int blocks_per_cu = 16;
     int debug_flags = 0;
+    int vpacket_screening = -1;  // v-packet screening on the prefix sums of tau (tau_prefix.hpp): -1 automatic, 0 off, 1 on
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
     long long log_capacity = 2500000000LL;  // upper bound of the line-visit records per epoch and buffer set of the wave kernel (24 B + 4 B + 4 B each)
     bool log_capacity_user = false;         // set through the log_capacity option (otherwise also bounded by the free device memory)
@@ -607,6 +611,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     for (auto &b : ctx->li_i64) b.release();
     ctx->li_rec.release();
     ctx->cum16.release(); ctx->rec16.release(); ctx->quad_info.release(); ctx->line_block_c.release();
+    ctx->tau_pfx.release(); ctx->tau_rowsum.release();
     ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
     ctx->vq_req.release(); ctx->vq_items.release(); ctx->vq_count.release(); ctx->vq_jsave.release();
     if (ctx->suspended_host) (void)hipHostFree(ctx->suspended_host);
@@ -634,6 +639,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "estimator_copies") { ctx->est_copies = std::max(1, std::min(8, (int)value)); ctx->est_valid = false; }
     else if (n == "vpacket_log_capacity") { ctx->vlog_capacity = value; ctx->vlog_capacity_user = value > 0; }
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
+    else if (n == "vpacket_screening") ctx->vpacket_screening = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
     else if (n == "lane_sweep_min_active") ctx->ls_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "lane_sweep_max_steps") ctx->ls_max_steps = (int)std::max<long long>(1, value);
@@ -770,6 +776,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         }
     }
     ctx->have_walk_tables = false;
+    ctx->pfx_valid = false;  // (the prefix sums of the new tau table are built by the first propagate call that traces v-packets)
     if (macro && E > 1 && !ctx->prob_negative) {
         // compact tables of the per-lane macro-atom walk (walk_tables.hpp): blocks at 16-byte aligned compact offsets
         const size_t n_levels = E - 1;
@@ -1218,6 +1225,36 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         P.delta_nu = F.delta_nu; P.vhist = F.vhist;
         P.bucket_first = ctx->bucket_first.as<int>(); P.bucket_shift = ctx->bucket_shift; P.bucket_n = ctx->bucket_n;
         P.bucket_kmin = ctx->bucket_kmin;
+        // v-packet screening (tau_prefix.hpp): with the default survival probability 0 a v-packet whose optical depth passes
+        // tau_russian is dropped whatever the depth was -- decided from prefix sums, two reads per shell crossing
+        P.tau_pfx = P.tau_rowsum = nullptr;
+        // It pays where a shell crossing passes many lines (two prefix reads against ~40 optical depths on the 100-shell x 5e5-line
+        // shape: 1.8x - 2.1x); on the tardis_example shape (~12 lines per crossing, most v-packets leave the grid alive) the
+        // screening is a second trace on top of the first: -36 % (profiles/r03_vpacket_screening.txt).  "vpacket_screening" 0 / 1
+        // overrides the automatic choice.
+        const bool screen_auto = (long long)ctx->n_lines >= 2500LL * (long long)ctx->n_shells;
+        const bool screen = ctx->vpacket_screening < 0 ? screen_auto : ctx->vpacket_screening != 0;
+        if (vpk && c.survival_probability == 0.0 && screen && !(ctx->debug_flags & 33554432)) {
+            if (!ctx->pfx_valid) {
+                const size_t S = (size_t)ctx->n_shells, L = (size_t)ctx->n_lines;
+                HIP_TRY(ctx, ctx->tau_pfx.ensure((S * (L + 1) + 8) * sizeof(double)));  // (+8: the four-entry windows of the screening)
+                HIP_TRY(ctx, ctx->tau_rowsum.ensure(S * sizeof(double)));
+                int *flag = nullptr;
+                HIP_TRY(ctx, hipMalloc((void **)&flag, sizeof(int)));
+                hipError_t e0 = hipMemsetAsync(flag, 0, sizeof(int), ctx->stream);
+                hipLaunchKernelGGL(mc::tau_prefix_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, ctx->tau_t.as<double>(), (int)L,
+                                   ctx->tau_pfx.as<double>(), ctx->tau_rowsum.as<double>(), flag);
+                int neg = 0;
+                hipError_t e1 = hipGetLastError();
+                hipError_t e2 = hipMemcpyAsync(&neg, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+                hipError_t e3 = hipStreamSynchronize(ctx->stream);
+                (void)hipFree(flag);
+                HIP_TRY(ctx, e0); HIP_TRY(ctx, e1); HIP_TRY(ctx, e2); HIP_TRY(ctx, e3);
+                ctx->pfx_negative = neg != 0;
+                ctx->pfx_valid = true;
+            }
+            if (!ctx->pfx_negative) { P.tau_pfx = ctx->tau_pfx.as<double>(); P.tau_rowsum = ctx->tau_rowsum.as<double>(); }
+        }
         // macro-atom jumps of the wave kernel (macroatom chains and the single jump of downbranch alike): per-lane walk on the
         // compact tables (walk_tables.hpp); debug flag 8192 keeps the cooperative group scan of the fp64 running sums (macroatom) /
         // the fp64 search (downbranch), 128 the per-lane search in them (both for cross-checks)
