@@ -53,17 +53,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 T_INNER = 1.0e4        # K, synthetic.make_problem's default photosphere temperature
 
 
-def algorithmic_bytes(c: dict, part: str = "step") -> float:
+def algorithmic_bytes(c: dict, part: str = "step", screened: bool = False) -> float:
     """48 B per line visit (nu_line 8 + tau 8 + the read-modify-writes of j_blue and Edotlu, 16 each), 56 B
     per event, 8 B per macro-atom transition examined, 16 B per v-packet line visit, 56 B of per-packet I/O.
 
     part = "step": everything a Monte Carlo iteration moves.  With the wave kernel the line-estimator read-modify-writes
     are not done by the propagation kernel (it logs one record per trace, the accumulate kernel applies them), so the
-    dominant kernel's own share is part = "propagate": 16 B per line visit + the rest; part = "estimators": 32 B per visit."""
+    dominant kernel's own share is part = "propagate": 16 B per line visit + the rest; part = "estimators": 32 B per visit.
+
+    screened = True: the v-packet screening (csrc/tau_prefix.hpp) decides nearly every v-packet from two prefix reads per shell
+    crossing instead of its line visits, so the 16 B x Vv term no longer describes bytes any algorithm has to move: it is left out
+    (a LOWER bound of the traffic: the crossings themselves are not counted) and the SURVEY figure is reported beside it."""
     per_visit = {"step": 48.0, "propagate": 16.0, "estimators": 32.0}[part]
     if part == "estimators":
         return per_visit * c["line_visits"]
-    return (per_visit * c["line_visits"] + 56.0 * c["events"] + walk_bytes(c) + 16.0 * c["vpacket_line_visits"]
+    return (per_visit * c["line_visits"] + 56.0 * c["events"] + walk_bytes(c) + 16.0 * c["vpacket_line_visits"] * (0.0 if screened else 1.0)
             + 56.0 * c["packets"])
 
 
@@ -217,7 +221,9 @@ def main():
         },
     }
     if pg.rank == 0:
-        out["roofline"] = roofline_block(eng, counters, ktimes, last_ms, P, measured_traffic(args, P, max(ktimes["launches"], 1)))
+        out["roofline"] = roofline_block(eng, counters, ktimes, last_ms, P, measured_traffic(args, P, max(ktimes["launches"], 1)),
+                                         screened=kw.get("n_vpackets", 0) > 0 and kw["n_lines"] >= 2500 * kw["n_shells"]
+                                         and not any(o.startswith("vpacket_screening=0") for o in args.option))
         if n_gpus == 1:
             n_cpu = args.cpu_sample if args.cpu_sample is not None else default_cpu_sample(kw)
             if n_cpu > 0:
@@ -242,7 +248,7 @@ def main():
     pg.destroy()
 
 
-def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, traffic) -> dict:
+def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, traffic, screened: bool = False) -> dict:
     """`roofline` of one workload: the dominant kernel = the propagation kernel; its launches of one step are timed with HIP
     events on the stream they run on."""
     launches = max(ktimes["launches"], 1)
@@ -252,11 +258,16 @@ def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, tr
                 3: "propagate_wave_kernel (lane sweeps)", 4: "propagate_wave_kernel (volley queue)"}.get(variant, f"variant {variant}")
     kernel_ms = ktimes["propagate_ms"] / launches
     # the dominant kernel's own algorithmic bytes (see algorithmic_bytes) over its HIP-event duration
-    bytes_per_launch = algorithmic_bytes(counters, "propagate" if wave else "step") / launches
+    bytes_per_launch = algorithmic_bytes(counters, "propagate" if wave else "step", screened) / launches
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    step_bytes = algorithmic_bytes(counters, "step")
+    step_bytes = algorithmic_bytes(counters, "step", screened)
     step_achieved = step_bytes / (last_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    survey = None
+    if screened:
+        b = algorithmic_bytes(counters, "propagate" if wave else "step", False) / launches
+        survey = {"algorithmic_bytes_per_launch": b, "achieved": b / (kernel_ms * 1e-3) / 1e9, "frac": b / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "note": "SURVEY 8(d) byte model incl. 16 B per v-packet line visit -- lines the screening no longer reads; context only"}
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "survey_model_with_vpacket_visits": survey,
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": f"{dominant} (dominant kernel of a step)", "kernel_ms": kernel_ms,
             "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -301,7 +312,9 @@ def extra_leg(device: int, name: str, kw: dict, P: int, steps: int, warmup: int,
                        f"{kw.get('n_vpackets', 0)} v-packets, tracking {'on' if track else 'off'}, macro-atom blocks "
                        f"{level_sizes} (rows per block: median {int(np.median(sizes))}, max {int(sizes.max())})",
            "value": P * steps / elapsed, "unit": "packets/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
-           "setup_s": t_build, "roofline": roofline_block(eng, counters, ktimes, last_ms, P, None)}
+           "setup_s": t_build,
+           "roofline": roofline_block(eng, counters, ktimes, last_ms, P, None,
+                                      screened=kw.get("n_vpackets", 0) > 0 and kw["n_lines"] >= 2500 * kw["n_shells"])}
     if cpu_sample > 0:
         leg["cpu_sample"] = cpu_baseline(prob, eng, P, radius, min(cpu_sample, P), single_thread=False)
     eng.close()

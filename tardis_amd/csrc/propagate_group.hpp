@@ -545,11 +545,15 @@ __device__ __forceinline__ int vp_screen(const GroupArgs &P, const GroupRng<G> &
 {
     const int L = P.n_lines, S = P.n_shells;
     const double t = P.t_exp;
+    // (the kernel is half bound by its VALU instructions at ~12 live lanes per wave: the divisions by t and by nu -- constant along
+    // a v-packet -- take the exact three-instruction form of mc_device.hpp where their operands allow it)
+    const double rcp_t = 1.0 / t, rcp_nu = 1.0 / nu;
+    const bool fast_t = mid_range(t), fast_nu = mid_range(nu);
     typedef double dbl2 __attribute__((ext_vector_type(2), aligned(8)));
     struct Crossing { double d_boundary, comov_nu, tau_cont; int delta, bucket_e; };
     auto geometry = [&](double rr, double mm, int sh, Crossing &c) {
         distance_boundary(rr, mm, geo[sh], geo[S + sh], c.d_boundary, c.delta);
-        const double dop = doppler_factor<FULL>(rr / t, mm);
+        const double dop = doppler_factor<FULL>((fast_t && mid_range(rr)) ? exact_div<true>(rr, t, rcp_t) : rr / t, mm);
         c.comov_nu = nu * dop;
         double chi_cont = geo[2 * S + sh] * P.sigma_thomson;
         if (FULL) chi_cont *= dop;
@@ -586,9 +590,15 @@ __device__ __forceinline__ int vp_screen(const GroupArgs &P, const GroupRng<G> &
             if (!(cur.d_boundary <= d_line)) {
                 e = max(cur.bucket_e, start + 1);
                 if (e > L - 1) e = L - 1;
+                // calculate_distance_line (calculate_distances.py:66-112) of a line after `start` (those cannot raise: the list is sorted)
                 auto stops_at_nu = [&](int k, double nl) -> bool {
                     double d;
-                    (void)distance_line<FULL>(nu, r, mu, cur.comov_nu, k == L - 1, nl, t, d);
+                    if (FULL) (void)distance_line<FULL>(nu, r, mu, cur.comov_nu, k == L - 1, nl, t, d);
+                    else {
+                        const double nu_diff = cur.comov_nu - nl;
+                        const double q = (fast_nu && mid_range(nu_diff)) ? exact_div<true>(nu_diff, nu, rcp_nu) : nu_diff / nu;
+                        d = (k == L - 1) ? MISS_DISTANCE : ((fabs(q) < CLOSE_LINE_THRESHOLD) ? 0.0 : q * C_LIGHT * t);
+                    }
                     return cur.d_boundary <= d;
                 };
                 auto stops_at = [&](int k) -> bool { return stops_at_nu(k, P.nu_line[(unsigned)k]); };
