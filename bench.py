@@ -28,7 +28,7 @@ workload, with the GPU-vs-CPU parity of that sample) and `boundary` (one full dr
 `transport.montecarlo_transport_with_vpackets` -- host arrays in, upload, set_opacity, propagate, results out -- on
 a bounded packet count: the PCIe-inclusive rate; never `value`).  The default N = 1 line also carries `extra`: the same
 timed-step structure on (a) the headline's tables with heavy-tailed macro-atom blocks and (b) BASELINE configs[4]'s table
-shape (100 shells, macroatom, ten v-packets per interaction) at 3e6 packets, each with its own `roofline` and the parity of a
+shape (100 shells, macroatom, ten v-packets per interaction) at 1e7 packets, each with its own `roofline` and the parity of a
 small sample against the CPU oracle (`--no-extra` skips them).
 """
 from __future__ import annotations
@@ -241,7 +241,7 @@ def main():
         #     ten v-packets per interaction -- at a packet count that keeps the whole run within minutes
         out["extra"] = {
             "heavy_tail": extra_leg(dev, "configs[2] tables, heavy-tailed blocks", synthetic.BASELINE_CONFIGS[3], P, 2, 1, "heavy", 20_000, True),
-            "config5_shape": extra_leg(dev, "configs[4] table shape", synthetic.BASELINE_CONFIGS[5], 3_000_000, 2, 1, "uniform", 3_000, True),
+            "config5_shape": extra_leg(dev, "configs[4] table shape", synthetic.BASELINE_CONFIGS[5], 10_000_000, 2, 1, "uniform", 3_000, True),
         }
     if pg.rank == 0:
         print(json.dumps(out), flush=True)

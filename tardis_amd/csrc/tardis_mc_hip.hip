@@ -1166,12 +1166,47 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // relativity) and no volleys run.  On the macroatom shape (5e5 lines, ~36 lines per trace) the lane sweeps overtook the
     // group sweeps once the walk ran per lane on the compact tables and a call became epochs over one packet supply
     // (19.3 vs 13.4 Mpkt/s at 2e7 packets): the group sweeps' 280 instructions per 16-line step had become the bound.
+    // v-packet screening (tau_prefix.hpp): with the default survival probability 0 a v-packet whose optical depth passes
+    // tau_russian is dropped whatever the depth was -- decided from prefix sums, two reads per shell crossing.
+    // It pays where a shell crossing passes many lines (two prefix reads against ~40 optical depths on the 100-shell x 5e5-line
+    // shape: 1.7x - 2.1x); on the tardis_example shape (~12 lines per crossing, most v-packets leave the grid alive) the
+    // screening is a second trace on top of the first: -36 % (profiles/r03_vpacket_screening.txt).  "vpacket_screening" 0 / 1
+    // overrides the automatic choice.
+    bool screen_on = false;
+    {
+        const bool screen_auto = (long long)ctx->n_lines >= 2500LL * (long long)ctx->n_shells;
+        const bool screen = ctx->vpacket_screening < 0 ? screen_auto : ctx->vpacket_screening != 0;
+        if (vpk && c.survival_probability == 0.0 && screen && !(ctx->debug_flags & 33554432)) {
+            if (!ctx->pfx_valid) {
+                const size_t S = (size_t)ctx->n_shells, L = (size_t)ctx->n_lines;
+                HIP_TRY(ctx, ctx->tau_pfx.ensure((S * (L + 1) + 8) * sizeof(double)));  // (+8: the four-entry windows of the screening)
+                HIP_TRY(ctx, ctx->tau_rowsum.ensure(S * sizeof(double)));
+                int *flag = nullptr;
+                HIP_TRY(ctx, hipMalloc((void **)&flag, sizeof(int)));
+                hipError_t e0 = hipMemsetAsync(flag, 0, sizeof(int), ctx->stream);
+                hipLaunchKernelGGL(mc::tau_prefix_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, ctx->tau_t.as<double>(), (int)L,
+                                   ctx->tau_pfx.as<double>(), ctx->tau_rowsum.as<double>(), flag);
+                int neg = 0;
+                hipError_t e1 = hipGetLastError();
+                hipError_t e2 = hipMemcpyAsync(&neg, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+                hipError_t e3 = hipStreamSynchronize(ctx->stream);
+                (void)hipFree(flag);
+                HIP_TRY(ctx, e0); HIP_TRY(ctx, e1); HIP_TRY(ctx, e2); HIP_TRY(ctx, e3);
+                ctx->pfx_negative = neg != 0;
+                ctx->pfx_valid = true;
+            }
+            screen_on = !ctx->pfx_negative;
+        }
+    }
     const bool prefer_lane_sweeps = !c.enable_full_relativity && !vpk;
     // With v-packets the wave kernel's pooled volleys win where a v-packet crosses few shells and few lines (the tardis_example
     // shape: 8.0 vs 5.2 Mpkt/s); on finer grids and longer line lists the group kernel -- every lane of a packet's group traces one
     // v-packet of the volley, no speculation on the draw positions -- was measured 1.2x to 2.2x ahead
     // (profiles/r02_vpacket_kernel_choice.txt).
-    const bool vpk_wave = vpk && ctx->n_shells <= 30 && ctx->n_lines <= 100000;
+    // With the screening the v-packets of such a shape are half of the wave kernel's pass instead of nearly all of it, and its
+    // lane-per-packet event code wins once the call is long enough to amortise its drain: 1.39-1.46 vs 1.33 Mpkt/s at 3e6 packets of
+    // the configs[4] shape, 0.63 vs 1.10 at 1e6 (profiles/r03_vpacket_screening.txt).
+    const bool vpk_wave = vpk && ((ctx->n_shells <= 30 && ctx->n_lines <= 100000) || (screen_on && ctx->n_packets >= 2500000));
     int variant = ctx->variant >= 0 ? ctx->variant
                                     : ((vpk && c.number_of_vpackets > 32) ? 0 : (vpk ? (vpk_wave ? 2 : 1) : (prefer_lane_sweeps ? 3 : 2)));
     if (ctx->prob_negative && (variant == 2 || variant == 3)) variant = 1;  // (the wave kernel searches the monotone running sums)
@@ -1237,36 +1272,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         P.delta_nu = F.delta_nu; P.vhist = F.vhist;
         P.bucket_first = ctx->bucket_first.as<int>(); P.bucket_shift = ctx->bucket_shift; P.bucket_n = ctx->bucket_n;
         P.bucket_kmin = ctx->bucket_kmin;
-        // v-packet screening (tau_prefix.hpp): with the default survival probability 0 a v-packet whose optical depth passes
-        // tau_russian is dropped whatever the depth was -- decided from prefix sums, two reads per shell crossing
-        P.tau_pfx = P.tau_rowsum = nullptr;
-        // It pays where a shell crossing passes many lines (two prefix reads against ~40 optical depths on the 100-shell x 5e5-line
-        // shape: 1.8x - 2.1x); on the tardis_example shape (~12 lines per crossing, most v-packets leave the grid alive) the
-        // screening is a second trace on top of the first: -36 % (profiles/r03_vpacket_screening.txt).  "vpacket_screening" 0 / 1
-        // overrides the automatic choice.
-        const bool screen_auto = (long long)ctx->n_lines >= 2500LL * (long long)ctx->n_shells;
-        const bool screen = ctx->vpacket_screening < 0 ? screen_auto : ctx->vpacket_screening != 0;
-        if (vpk && c.survival_probability == 0.0 && screen && !(ctx->debug_flags & 33554432)) {
-            if (!ctx->pfx_valid) {
-                const size_t S = (size_t)ctx->n_shells, L = (size_t)ctx->n_lines;
-                HIP_TRY(ctx, ctx->tau_pfx.ensure((S * (L + 1) + 8) * sizeof(double)));  // (+8: the four-entry windows of the screening)
-                HIP_TRY(ctx, ctx->tau_rowsum.ensure(S * sizeof(double)));
-                int *flag = nullptr;
-                HIP_TRY(ctx, hipMalloc((void **)&flag, sizeof(int)));
-                hipError_t e0 = hipMemsetAsync(flag, 0, sizeof(int), ctx->stream);
-                hipLaunchKernelGGL(mc::tau_prefix_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, ctx->tau_t.as<double>(), (int)L,
-                                   ctx->tau_pfx.as<double>(), ctx->tau_rowsum.as<double>(), flag);
-                int neg = 0;
-                hipError_t e1 = hipGetLastError();
-                hipError_t e2 = hipMemcpyAsync(&neg, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-                hipError_t e3 = hipStreamSynchronize(ctx->stream);
-                (void)hipFree(flag);
-                HIP_TRY(ctx, e0); HIP_TRY(ctx, e1); HIP_TRY(ctx, e2); HIP_TRY(ctx, e3);
-                ctx->pfx_negative = neg != 0;
-                ctx->pfx_valid = true;
-            }
-            if (!ctx->pfx_negative) { P.tau_pfx = ctx->tau_pfx.as<double>(); P.tau_rowsum = ctx->tau_rowsum.as<double>(); }
-        }
+        P.tau_pfx = screen_on ? ctx->tau_pfx.as<double>() : nullptr;
+        P.tau_rowsum = screen_on ? ctx->tau_rowsum.as<double>() : nullptr;
         // macro-atom jumps of the wave kernel (macroatom chains and the single jump of downbranch alike): per-lane walk on the
         // compact tables (walk_tables.hpp); debug flag 8192 keeps the cooperative group scan of the fp64 running sums (macroatom) /
         // the fp64 search (downbranch), 128 the per-lane search in them (both for cross-checks)

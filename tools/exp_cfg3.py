@@ -20,6 +20,8 @@ if os.environ.get("EXP_SHAPE") == "config2v":
     shape = dict(n_shells=20, n_lines=30_000, line_interaction_type="downbranch", n_vpackets=10)
 if os.environ.get("EXP_SHAPE") == "config5":
     shape = dict(n_shells=100, n_lines=500_000, line_interaction_type="macroatom", n_vpackets=10)
+if os.environ.get("EXP_NV") is not None:
+    shape["n_vpackets"] = int(os.environ["EXP_NV"])
 if os.environ.get("EXP_LOG_TAU"):  # thinner / thicker lines than the default synthetic ejecta (log10 of the mean Sobolev depth)
     shape["log_tau_mean"] = float(os.environ["EXP_LOG_TAU"])
 if os.environ.get("EXP_NE0"):
