@@ -436,6 +436,59 @@ def test_config5_shape_small(oracle):
 
 
 @pytest.mark.gpu
+def test_config5_shape_at_size_properties(oracle):
+    """BASELINE configs[4] shape at 3e6 packets (2.4e9 v-packets; its own count is 6.25e7 per GPU): the call the engine routes to the
+    wave kernel's pooled volleys with the v-packet screening.  Size-independent properties: every packet terminates, the counters add
+    up, the group kernel and the run without the screening reproduce it bit for bit per packet (and the v-packet spectrum to the
+    summation order), and the first 2 000 packets equal the oracle."""
+    from tardis_amd.engine import Engine
+    P = 3_000_000
+    prob = synthetic.make_problem(seed=1, n_packets=1, n_shells=100, n_lines=500_000, line_interaction_type="macroatom", n_vpackets=10)
+    radius = float(prob.geometry.r_inner[0])
+    eng = Engine(0)
+    eng.set_option("track_last_interaction", 0)
+    eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+    eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
+    eng.create_blackbody_packets(P, radius, 1.0e4)
+
+    def run(**options):
+        for k, v in options.items():
+            eng.set_option(k, v)
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        r = eng.get_results(track_last_interaction=False, want_line_estimators=False)
+        variant = eng.last_variant()
+        for k in options:
+            eng.set_option(k, -1 if k in ("variant", "vpacket_screening") else 0)
+        return r, variant
+
+    a, va = run()
+    assert va == 2  # wave kernel, pooled volleys (the screening makes it the faster one from 2.5e6 packets per call on)
+    c = a.counters
+    assert c["packets"] == P and c["events"] >= P and c["vpackets"] > 100 * P and c["vpacket_line_visits"] > 50 * c["vpackets"]
+    assert c["rng_draws"] >= c["vpackets"] + c["events"]
+    assert not np.any(a.output_energies == -99.0) and np.all(np.isfinite(a.output_nus)) and np.all(a.output_nus > 0)
+    assert np.all(a.v_packets_energy_hist >= 0) and a.v_packets_energy_hist.sum() > 0 and np.all(a.j_estimator > 0)
+    b, vb = run(variant=1)              # group kernel, screening on
+    d, vd = run(vpacket_screening=0, variant=1)   # line-by-line traces only
+    assert vb == 1 and vd == 1
+    for other in (b, d):
+        assert np.array_equal(a.output_nus, other.output_nus) and np.array_equal(a.output_energies, other.output_energies)
+        assert a.counters["vpacket_line_visits"] == other.counters["vpacket_line_visits"] and a.counters["rng_draws"] == other.counters["rng_draws"]
+        assert_allclose(other.v_packets_energy_hist, a.v_packets_energy_hist, rtol=1e-10, atol=1e-300)
+        assert_allclose(other.j_estimator, a.j_estimator, rtol=EST_RTOL)
+    # the first packets against the oracle (per-packet results do not depend on batching)
+    n = 2_000
+    eng.create_blackbody_packets(P, radius, 1.0e4, first=0, count=n)
+    pk = eng.get_packets()
+    eng.close()
+    sub = st.PacketCollection(pk["initial_radii"], pk["initial_nus"], pk["initial_mus"], pk["initial_energies"], pk["packet_seeds"],
+                              4 * np.pi * st.SIGMA_SB * radius**2 * 1.0e4**4)
+    ref = oracle.run(sub, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration, prob.spectrum_frequency_grid,
+                     math_mode=oracle.MATH_PORTABLE, n_threads=oracle.max_threads(), track_last_interaction=False)
+    assert np.array_equal(a.output_nus[:n], ref.output_nus) and np.array_equal(a.output_energies[:n], ref.output_energies)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["downbranch", "macroatom"])
 def test_negative_transition_probability_keeps_the_serial_walk(oracle, mode):
     """The wave kernel searches the running sums of the transition probabilities, which presumes they are monotone.  A table
