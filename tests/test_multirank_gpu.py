@@ -49,3 +49,12 @@ def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path):
     for k in ("j_estimator", "nu_bar_estimator", "j_blue_shell_sums", "edotlu_shell_sums", "j_blue_line_sums"):
         assert_allclose(a[k], b[k], rtol=1e-10, err_msg=k)
     assert np.all(a["j_estimator"] > 0)
+    # --scaling strong: the packet count is the job's (BASELINE configs[3]: 1e8 packets shared by 8 GPUs), every rank takes its share
+    strong = tmp_path / "strong.npz"
+    line3 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--packets", str(2 * P), "--scaling", "strong",
+                  "--all-on-device", "0", "--dump-estimators", str(strong)] + common)
+    assert line3["scaling"] == "strong" and line3["config"]["packets_per_gpu"] == P and "strong scaling" in line3["config"]["parallelism"]
+    c = np.load(strong)
+    for k in ("j_estimator", "nu_bar_estimator", "j_blue_shell_sums"):
+        assert_allclose(c[k], b[k], rtol=1e-10, err_msg=k)
