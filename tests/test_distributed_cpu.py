@@ -64,3 +64,31 @@ def test_two_rank_job_matches_single_process(tmp_path, oracle, backend, launcher
         assert_allclose(p["j_blue"], ref.j_blue_estimator, rtol=1e-12)
         assert_allclose(p["edotlu"], ref.edotlu_estimator, rtol=1e-12)
     assert np.array_equal(parts[0]["j_blue"], parts[1]["j_blue"])
+
+
+def test_control_plane_with_eight_ranks(tmp_path):
+    """The TCP hub at the world size of the driver's scaling run (N = 8): rendezvous through the port file, broadcast from rank 0
+    and from another rank, max-over-ranks, a summed array, barrier, orderly shutdown."""
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import numpy as np\n"
+        "from tardis_amd import distributed\n"
+        "pg = distributed.init_from_env()\n"
+        "assert pg.world_size == 8 and 'torch' not in sys.modules\n"
+        "assert pg.broadcast_bytes(bytes(range(128)) if pg.rank == 0 else None, src=0) == bytes(range(128))\n"
+        "assert pg.broadcast_bytes(b'five' if pg.rank == 5 else None, src=5) == b'five'\n"
+        "assert pg.max_float(float(pg.rank)) == 7.0\n"
+        "a = np.full((3, 4), float(pg.rank + 1)); pg.sum_arrays_([a]); assert np.all(a == 36.0)\n"
+        "for _ in range(20): pg.barrier()\n"
+        "pg.destroy()\n"
+        "print('rank', pg.rank, 'ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="8")
+    env.pop("TARDIS_AMD_CONTROL_PORT", None)
+    # all ranks are children of this process: the port file is named after (MASTER_PORT, our pid), as under the launcher's agent
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(k), LOCAL_RANK=str(k)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k in (3, 7, 1, 0, 2, 6, 5, 4)]
+    for p in procs:
+        o, _ = p.communicate(timeout=300)
+        assert p.returncode == 0 and "ok" in o, o
