@@ -1869,11 +1869,14 @@ template <bool FULL>
 __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__restrict__ W)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    double *geo = reinterpret_cast<double *>(lds_raw);  // r_inner | r_outer | n_e
+    double *geo = reinterpret_cast<double *>(lds_raw);  // r_inner | r_outer | n_e | tau row sums (v-packet screening)
     const GroupArgs &P = W->P;
     const int S = P.n_shells;
     const int lane = threadIdx.x;
-    for (int s = lane; s < S; s += 64) { geo[s] = P.r_inner[s]; geo[S + s] = P.r_outer[s]; geo[2 * S + s] = P.n_e[s]; }
+    for (int s = lane; s < S; s += 64) {
+        geo[s] = P.r_inner[s]; geo[S + s] = P.r_outer[s]; geo[2 * S + s] = P.n_e[s];
+        geo[3 * S + s] = P.tau_rowsum ? P.tau_rowsum[s] : 0.0;
+    }
     __syncthreads();
     const unsigned n_items = W->vq_count[0];
     const int n_v = (int)P.n_vpackets;
@@ -1889,6 +1892,10 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
     double v_rcp_nu = 0.0;
     bool v_fast = false;
     vs.r = vs.mu = vs.nu = vs.energy = vs.tau = vs.mu0 = 0.0; vs.shell = 0; vs.next_line = 0;
+    // screening (tau_prefix.hpp), as in the pooled volleys: an item predicted to be dropped is first traced on the prefix sums
+    bool screening = false;
+    double v_margin = 0.0, v0_r = 0.0, v0_energy = 0.0;
+    int v0_shell = 0, v0_line = 0;
     for (;;) {
         const unsigned long long free_l = __ballot(!tracing);
         bool take = false;
@@ -1958,6 +1965,8 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
             vs.tau = 0.0; vs.shell = rq->shell; vs.next_line = rq->next_line;
             my_visits = 0;
             tracing = true;
+            screening = P.tau_pfx != nullptr && ((f_pred >> i) & 1u) != 0u;
+            v_margin = 0.0; v0_r = f_r; v0_energy = vs.energy; v0_shell = vs.shell; v0_line = vs.next_line;
         }
         if (tracing) {
             const double *dr = W->vq_req[my_slot].draws;
@@ -1967,7 +1976,15 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
                 return d;
             };
             int draws_left = w_avail - (w_q + w_used);
-            const int st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, v_rcp_nu, v_fast, geo, my_visits);
+            int st;
+            if (screening) {
+                st = vp_screen_step<FULL>(P, wdraw, draws_left, vs, v_margin, v_rcp_nu, v_fast, geo, my_visits);
+                if (st == 2) {  // not decided on the prefix sums: again, line by line
+                    vs.r = v0_r; vs.mu = vs.mu0; vs.energy = v0_energy; vs.tau = 0.0; vs.shell = v0_shell; vs.next_line = v0_line;
+                    my_visits = 0; w_used = 0; screening = false; st = 0;
+                }
+            } else
+                st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, v_rcp_nu, v_fast, geo, my_visits);
             if (st != 0) {
                 VpResult r;
                 r.nu = vs.nu; r.energy = st == 1 ? vs.energy * mcm::exp(-vs.tau) : 0.0; r.mu0 = vs.mu0;

@@ -1485,7 +1485,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
                 HIP_TRY(ctx, hipGetLastError());
                 if (vq_on) {  // the v-packets this launch requested (the item count is read on the device: an empty list costs a launch)
-                    const size_t geo_lds = (size_t)3 * (size_t)ctx->n_shells * sizeof(double);
+                    const size_t geo_lds = (size_t)4 * (size_t)ctx->n_shells * sizeof(double);
                     const int tracer_waves = cus * 4 * ctx->vq_tracer_waves_per_simd;
                     if (full) hipLaunchKernelGGL(mc::vpacket_trace_kernel<true>, dim3(tracer_waves), dim3(64), geo_lds, st, (const mc::WaveCold *)wc_dev);
                     else hipLaunchKernelGGL(mc::vpacket_trace_kernel<false>, dim3(tracer_waves), dim3(64), geo_lds, st, (const mc::WaveCold *)wc_dev);
