@@ -28,46 +28,9 @@
 
 namespace mc {
 
-// ---- cache-policy experiments (debug_flags): the streaming data of the kernel -- log records, tracker
-// records, MT19937 words, tau rows, walk tables -- passes through the same 4 MB L2 per XCD that should be holding nu_line.
-//   65536   stores of log / tracker / MT19937 words non-temporal (nt)
-//   131072  the same stores write-through, line dropped from the L2 (sc0 sc1)
-//   262144  tau chunk loads nt          524288  walk table loads (cum16 window, rec16) nt        1048576  MT19937 state loads nt
-typedef unsigned pol_v4u __attribute__((ext_vector_type(4)));
-typedef unsigned pol_v2u __attribute__((ext_vector_type(2)));
-enum : int { POL_ST_NT = 65536, POL_ST_WT = 131072, POL_LD_TAU_NT = 262144, POL_LD_WALK_NT = 524288, POL_LD_MT_NT = 1048576 };
-__device__ __forceinline__ void pol_store16(void *p, pol_v4u v, int flags)
-{
-    if (flags & POL_ST_NT) __builtin_nontemporal_store(v, reinterpret_cast<pol_v4u *>(p));
-    else if (flags & POL_ST_WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-    else *reinterpret_cast<pol_v4u *>(p) = v;
-}
-__device__ __forceinline__ void pol_store8(void *p, pol_v2u v, int flags)
-{
-    if (flags & POL_ST_NT) __builtin_nontemporal_store(v, reinterpret_cast<pol_v2u *>(p));
-    else if (flags & POL_ST_WT) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-    else *reinterpret_cast<pol_v2u *>(p) = v;
-}
-__device__ __forceinline__ void pol_store4(void *p, unsigned v, int flags)
-{
-    if (flags & POL_ST_NT) __builtin_nontemporal_store(v, reinterpret_cast<unsigned *>(p));
-    else if (flags & POL_ST_WT) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-    else *reinterpret_cast<unsigned *>(p) = v;
-}
-template <class T>
-__device__ __forceinline__ void pol_store_struct(T *dst, const T &src, int flags)
-{
-    static_assert(sizeof(T) % 8 == 0, "8-byte granules");
-    if (!(flags & (POL_ST_NT | POL_ST_WT))) { *dst = src; return; }
-    const unsigned *w = reinterpret_cast<const unsigned *>(&src);
-    char *d = reinterpret_cast<char *>(dst);
-    constexpr int N16 = (alignof(T) >= 16) ? (int)(sizeof(T) / 16) : 0;
-#pragma unroll
-    for (int i = 0; i < N16; ++i) pol_store16(d + 16 * i, pol_v4u{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]}, flags);
-#pragma unroll
-    for (int i = 2 * N16; i < (int)(sizeof(T) / 8); ++i) pol_store8(d + 8 * i, pol_v2u{w[2 * i], w[2 * i + 1]}, flags);
-}
-
+// (Cache-policy hints on the kernel's streaming data -- non-temporal / write-through stores of log, tracker and MT19937 words,
+// non-temporal loads of the tau chunks, the walk tables and the MT19937 state -- were measured in round 3 behind run-time flags and
+// removed again: all neutral or slower, profiles/r03_cache_policy_ab.txt)
 constexpr int WV_STATE_STRIDE = 624;  // words between the MT19937 states of two packets
 constexpr int WV_RING = 8, WV_RING_VPK = 16;  // look-ahead doubles per packet (power of two; a refill adds 4, so it needs r_cnt <= 4).  16 with 8-double
                             // refills was measured: fewer refill rounds, but the extra 4 KiB of LDS costs the 12th wave of the CU
@@ -780,9 +743,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         const bool c_contig = cb + 8 <= MT_N;
         auto load_c = [&]() {  // wc[0..7] = regenerated words mt[(k0 + 397 + i) mod 624]
             if (c_contig) {
-                const bool nt = (H.debug_flags & POL_LD_MT_NT) != 0;
-                const v4u lo = nt ? __builtin_nontemporal_load(reinterpret_cast<const v4u_a4 *>(st + cb)) : *reinterpret_cast<const v4u_a4 *>(st + cb);
-                const v4u hi = nt ? __builtin_nontemporal_load(reinterpret_cast<const v4u_a4 *>(st + cb + 4)) : *reinterpret_cast<const v4u_a4 *>(st + cb + 4);
+                const v4u lo = *reinterpret_cast<const v4u_a4 *>(st + cb), hi = *reinterpret_cast<const v4u_a4 *>(st + cb + 4);
                 wc[0] = lo.x; wc[1] = lo.y; wc[2] = lo.z; wc[3] = lo.w; wc[4] = hi.x; wc[5] = hi.y; wc[6] = hi.z; wc[7] = hi.w;
             } else {
 #pragma unroll
@@ -816,9 +777,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 for (int i = 0; i < 8; ++i) wc[i] = wi[i];
             }
         } else {
-            const bool nt = (H.debug_flags & POL_LD_MT_NT) != 0;
-            const v4u lo = nt ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(st + k0)) : *reinterpret_cast<const v4u *>(st + k0);  // 32-byte aligned
-            const v4u hi = nt ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(st + k0 + 4)) : *reinterpret_cast<const v4u *>(st + k0 + 4);
+            const v4u lo = *reinterpret_cast<const v4u *>(st + k0), hi = *reinterpret_cast<const v4u *>(st + k0 + 4);  // 32-byte aligned
             wa[0] = lo.x; wa[1] = lo.y; wa[2] = lo.z; wa[3] = lo.w; wa[4] = hi.x; wa[5] = hi.y; wa[6] = hi.z; wa[7] = hi.w;
             wa[8] = st[(k0 + 8 == MT_N) ? 0 : k0 + 8];
             load_c();
@@ -831,8 +790,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         }
         v4u *dst = reinterpret_cast<v4u *>(st + k0);  // 32-byte aligned: k0 is a multiple of 8
         v4u lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
-        if (H.debug_flags & (POL_ST_NT | POL_ST_WT)) { pol_store16(dst, lo4, H.debug_flags); pol_store16(dst + 1, hi4, H.debug_flags); }
-        else { dst[0] = lo4; dst[1] = hi4; }
+        dst[0] = lo4; dst[1] = hi4;
         const int tail = (r_head + r_cnt) & (RING - 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) ring[((tail + q) & (RING - 1)) * 64 + lane] = GroupRng<8>::to_double(v[2 * q], v[2 * q + 1]);
@@ -969,8 +927,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     rec.n = (unsigned)n_visit;
                     if (my < log.region_capacity) {
                         const size_t slot = (size_t)blockIdx.x * log.region_capacity + my;
-                        pol_store_struct(&log.records[slot], rec, H.debug_flags);
-                        pol_store4(&log.keys[slot], (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE), H.debug_flags);
+                        log.records[slot] = rec;
+                        log.keys[slot] = (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE);
                     } else {  // region full (or no log): add the terms directly (slow path)
                         for (int k = 0; k < n_visit; ++k) {
                             const double f = FULL ? 1.0 : P.nu_line[(unsigned)(start + k)];
@@ -1076,18 +1034,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     const int nq = min(WALK_WINDOW_QUADS, n_quads - q_lo);
                     const uint4 *__restrict__ wp = reinterpret_cast<const uint4 *>(blk + 8 * q_lo);
                     uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
-                    if (H.debug_flags & POL_LD_WALK_NT) {
-                        auto ldnt = [&](int i) { const pol_v4u t = __builtin_nontemporal_load(reinterpret_cast<const pol_v4u *>(wp) + i); return make_uint4(t.x, t.y, t.z, t.w); };
-                        if (nq > 0) w0 = ldnt(0);
-                        if (nq > 1) w1 = ldnt(1);
-                        if (nq > 2) w2 = ldnt(2);
-                        if (nq > 3) w3 = ldnt(3);
-                    } else {
-                        if (nq > 0) w0 = wp[0];
-                        if (nq > 1) w1 = wp[1];
-                        if (nq > 2) w2 = wp[2];
-                        if (nq > 3) w3 = wp[3];
-                    }
+                    if (nq > 0) w0 = wp[0];
+                    if (nq > 1) w1 = wp[1];
+                    if (nq > 2) w2 = wp[2];
+                    if (nq > 3) w3 = wp[3];
                     const unsigned xx = x | (x << 16);
                     unsigned less = 0, gt = 0;
                     if (nq > 0) walk_count_quad(w0, xx, less, gt);
@@ -1300,7 +1250,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     rec.radius = p.r; rec.after_mu = p.mu;
                     rec.shell = p.shell; rec.type = type; rec.absorb = absorb_id; rec.emit = emit_id;
                     rec.count = trk_count; rec.valid = 1;
-                    pol_store_struct(&reinterpret_cast<TrackerRecord *>(W->D.li_rec)[chunk_first + pkt], rec, H.debug_flags);
+                    reinterpret_cast<TrackerRecord *>(W->D.li_rec)[chunk_first + pkt] = rec;
                 }
             }
             state = WS_NEED_TRACE;
@@ -1682,13 +1632,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     const double *__restrict__ pn = H.nu_line + (unsigned)s_line;
                     const double *__restrict__ pt = H.tau_t + (s_row + (unsigned)s_line);
                     double nl[LS_CHUNK], tl[LS_CHUNK];
-                    if (H.debug_flags & POL_LD_TAU_NT) {
 #pragma unroll
-                        for (int k = 0; k < LS_CHUNK; ++k) { nl[k] = pn[k]; tl[k] = __builtin_nontemporal_load(pt + k); }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < LS_CHUNK; ++k) { nl[k] = pn[k]; tl[k] = pt[k]; }
-                    }
+                    for (int k = 0; k < LS_CHUNK; ++k) { nl[k] = pn[k]; tl[k] = pt[k]; }
                     int adv = 0;  // lines of this chunk the trace has passed
                     const double comov = p.nu * dop;
                     // lines that provably do not stop the trace (see above); the first one that might is kept in f_nu / f_tau
