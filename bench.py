@@ -86,7 +86,11 @@ def walk_bytes(c: dict) -> float:
     return min(serial, 80.0 * jumps_lb)
 
 
+EXTRA_LEGS_DEADLINE_S = 270.0  # the extra legs (~25 s + ~30 s) only start while the whole run is younger than this
+
+
 def main():
+    t_run0 = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -225,12 +229,13 @@ def main():
                                          screened=kw.get("n_vpackets", 0) > 0 and kw["n_lines"] >= 2500 * kw["n_shells"]
                                          and not any(o.startswith("vpacket_screening=0") for o in args.option))
         if n_gpus == 1:
+            # (the legs below never take the headline line down with them: a failure is reported in their place)
             n_cpu = args.cpu_sample if args.cpu_sample is not None else default_cpu_sample(kw)
             if n_cpu > 0:
-                out["cpu_baseline"] = cpu_baseline(prob, eng, P, radius, min(n_cpu, P))
+                out["cpu_baseline"] = guarded(cpu_baseline, prob, eng, P, radius, min(n_cpu, P))
             n_b = args.boundary_packets if args.boundary_packets is not None else min(P, 10_000_000)
             if n_b > 0:
-                out["boundary"] = boundary_call(prob, eng, n_b, not args.no_tracking)
+                out["boundary"] = guarded(boundary_call, prob, eng, n_b, not args.no_tracking)
     eng.close()  # (frees the line-visit log before the extra legs allocate theirs)
     default_line = (n_gpus == 1 and args.config == 3 and args.level_sizes == "uniform" and not args.option and not args.no_tracking
                     and all(v is None for v in (args.packets, args.lines, args.shells, args.mode, args.vpackets, args.variant)))
@@ -239,13 +244,28 @@ def main():
         # (a) the headline's tables with heavy-tailed macro-atom blocks (what real atomic data looks like: a block is ALL
         #     transitions out of a level), same packet count; (b) BASELINE configs[4]'s table shape -- 100 shells, macroatom,
         #     ten v-packets per interaction -- at a packet count that keeps the whole run within minutes
+        def timely(*a):
+            if time.perf_counter() - t_run0 > EXTRA_LEGS_DEADLINE_S:
+                return {"skipped": f"the run was already {time.perf_counter() - t_run0:.0f} s old (the default line stays within minutes)"}
+            return guarded(extra_leg, *a)
+
         out["extra"] = {
-            "heavy_tail": extra_leg(dev, "configs[2] tables, heavy-tailed blocks", synthetic.BASELINE_CONFIGS[3], P, 2, 1, "heavy", 20_000, True),
-            "config5_shape": extra_leg(dev, "configs[4] table shape", synthetic.BASELINE_CONFIGS[5], 10_000_000, 2, 1, "uniform", 3_000, True),
+            "heavy_tail": timely(dev, "configs[2] tables, heavy-tailed blocks", synthetic.BASELINE_CONFIGS[3], P, 2, 1, "heavy", 20_000, True),
+            "config5_shape": timely(dev, "configs[4] table shape", synthetic.BASELINE_CONFIGS[5], 10_000_000, 2, 1, "uniform", 3_000, True),
         }
     if pg.rank == 0:
         print(json.dumps(out), flush=True)
     pg.destroy()
+
+
+def guarded(leg, *a, **kw):
+    """Run one of the side legs of the line; an exception becomes {"error": ...} instead of costing the headline."""
+    try:
+        return leg(*a, **kw)
+    except Exception as exc:  # noqa: BLE001 -- reported in the line
+        import traceback
+        print(f"bench.py: leg {leg.__name__} failed: {exc}\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, traffic, screened: bool = False) -> dict:
