@@ -64,6 +64,9 @@ CASES = {
                                  level_sizes="heavy", log_tau_mean=-2.0), {}),
     "downbranch_heavy_nv2": (dict(seed=32, n_packets=800, n_shells=10, n_lines=4000, line_interaction_type="downbranch",
                                   n_vpackets=2, level_sizes="heavy", log_tau_mean=-2.0), dict(ENABLE_VPACKET_TRACKING=True)),
+    "macroatom_heavy_fullrel_nv2": (dict(seed=33, n_packets=400, n_shells=8, n_lines=4000, line_interaction_type="macroatom",
+                                         n_vpackets=2, level_sizes="heavy", log_tau_mean=-2.0, enable_full_relativity=True),
+                                    dict(ENABLE_VPACKET_TRACKING=True)),
     # quirk (iii) of SURVEY 8a: disable_line_scattering with non-zero tau_sobolev (real runs zero tau first, opacity_solver.py:46-56)
     "scatter_disabled_lines_tau": (dict(seed=21, n_packets=300, n_shells=6, n_lines=400, line_interaction_type="scatter",
                                         disable_line_scattering=True), {}),
