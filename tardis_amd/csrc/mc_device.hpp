@@ -290,4 +290,81 @@ __device__ __forceinline__ void atomic_add_f64(double *p, double v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- address spaces.  A pointer the kernel LOADED from memory (a field of WaveCold / GroupArgs / DeviceProblem / EstimatorLog
+// read through the argument block) is a generic pointer to the compiler, and every access through it becomes a FLAT
+// instruction: it counts on the vector-memory AND the LDS counter and returns out of order against LDS accesses, so the
+// compiler can neither leave such a load in flight across an LDS access nor wait for "all but N" of them -- every wait turns
+// into a full drain (round 3's wave kernel: 189 flat_load against 20 global_load, 75 x `s_waitcnt vmcnt(0) lgkmcnt(0)`).
+// All of these pointers are device (global) memory; glob() says so at the point of use (the cast is free, the pointer itself
+// still comes out of a scalar load), gload / gstore move whole structures in the widest pieces their alignment allows (class
+// types cannot be copied through an address-space-qualified lvalue).
+// One trap, measured (profiles/r04_address_space_ab.txt): a load whose address is wave-uniform and provably global becomes a
+// SCALAR load; where that put a wave's bookkeeping into SGPRs for the whole kernel the event loop went from 45 to 215 spilled
+// VGPRs and lost 25 % -- such loads keep an opaque (vector) index, see the resume code of propagate_wave_kernel.
+#define MC_AS1 __attribute__((address_space(1)))
+#define MC_G MC_AS1
+template <class T> __device__ __forceinline__ MC_G T *glob(T *p) { return (MC_G T *)p; }
+template <class T> __device__ __forceinline__ T gload(const T *p)
+{
+    typedef unsigned gv4 __attribute__((ext_vector_type(4)));
+    typedef unsigned gv2 __attribute__((ext_vector_type(2)));
+    struct { unsigned w[sizeof(T) / 4]; } u;
+    static_assert(sizeof(T) % 4 == 0, "gload: whole dwords");
+    constexpr int N = (int)(sizeof(T) / 4);
+    if constexpr (alignof(T) >= 16 && N % 4 == 0) {
+        const MC_G gv4 *q = (const MC_G gv4 *)p;
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) { const gv4 t = q[i]; u.w[4 * i] = t.x; u.w[4 * i + 1] = t.y; u.w[4 * i + 2] = t.z; u.w[4 * i + 3] = t.w; }
+    } else if constexpr (alignof(T) >= 8 && N % 2 == 0) {
+        const MC_G gv2 *q = (const MC_G gv2 *)p;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) { const gv2 t = q[i]; u.w[2 * i] = t.x; u.w[2 * i + 1] = t.y; }
+    } else {
+        const MC_G unsigned *q = (const MC_G unsigned *)p;
+#pragma unroll
+        for (int i = 0; i < N; ++i) u.w[i] = q[i];
+    }
+    T r;
+    __builtin_memcpy(&r, u.w, sizeof(T));
+    return r;
+}
+template <class T> __device__ __forceinline__ void gstore(T *p, const T &v)
+{
+    typedef unsigned gv4 __attribute__((ext_vector_type(4)));
+    typedef unsigned gv2 __attribute__((ext_vector_type(2)));
+    struct { unsigned w[sizeof(T) / 4]; } u;
+    static_assert(sizeof(T) % 4 == 0, "gstore: whole dwords");
+    __builtin_memcpy(u.w, &v, sizeof(T));
+    constexpr int N = (int)(sizeof(T) / 4);
+    if constexpr (alignof(T) >= 16 && N % 4 == 0) {
+        MC_G gv4 *q = (MC_G gv4 *)p;
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) { gv4 t = {u.w[4 * i], u.w[4 * i + 1], u.w[4 * i + 2], u.w[4 * i + 3]}; q[i] = t; }
+    } else if constexpr (alignof(T) >= 8 && N % 2 == 0) {
+        MC_G gv2 *q = (MC_G gv2 *)p;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) { gv2 t = {u.w[2 * i], u.w[2 * i + 1]}; q[i] = t; }
+    } else {
+        MC_G unsigned *q = (MC_G unsigned *)p;
+#pragma unroll
+        for (int i = 0; i < N; ++i) q[i] = u.w[i];
+    }
+}
+__device__ __forceinline__ void gatomic_add_f64(double *p, double v)
+{
+    __hip_atomic_fetch_add((MC_AS1 __typeof__(*p) *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long gatomic_add_u64(unsigned long long *p, unsigned long long v)
+{
+    return __hip_atomic_fetch_add((MC_AS1 __typeof__(*p) *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned gatomic_add_u32(unsigned *p, unsigned v)
+{
+    return __hip_atomic_fetch_add((MC_AS1 __typeof__(*p) *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gatomic_min_i64(long long *p, long long v)
+{
+    __hip_atomic_fetch_min((MC_AS1 __typeof__(*p) *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace mc

@@ -423,15 +423,16 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
     // The step is bound by the latency of its dependent, uncoalesced loads, so everything whose address is known now is
     // requested first: the line at `start` and -- speculatively -- the first eight optical depths of the sum.
     const int start_c = min(start, L - 1);
-    const double *__restrict__ trow = P.tau_t + row + (unsigned)start_c;
-    const double nl_start = P.nu_line[(unsigned)start_c];
+    const MC_G double *__restrict__ trow = glob(P.tau_t) + row + (unsigned)start_c;
+    const MC_G double *__restrict__ nu_line_g = glob(P.nu_line);
+    const double nl_start = nu_line_g[(unsigned)start_c];
     // (two optical depths per load instruction; past the end of the table there is slack, and what lies beyond the lines of the
     // sum is replaced by +0.0 before it is used)
     typedef double tau2 __attribute__((ext_vector_type(2), aligned(8)));
     double tv[8];
 #pragma unroll
     for (int k = 0; k < 8; k += 2) {
-        const tau2 w = *reinterpret_cast<const tau2 *>(trow + k);
+        const tau2 w = *reinterpret_cast<const MC_G tau2 *>(trow + k);
         tv[k] = w.x; tv[k + 1] = w.y;
     }
     // trace_vpacket_within_shell (:82-175)
@@ -450,7 +451,7 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
     const double nu_thr = comov_nu - d_boundary * P.rcp_tc * v.nu;
     long long kk_b = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
     kk_b = kk_b < 0 ? 0 : (kk_b >= P.bucket_n ? P.bucket_n - 1 : kk_b);
-    const int bucket_e = P.bucket_first[kk_b];
+    const int bucket_e = glob(P.bucket_first)[kk_b];
     // calculate_distance_line (calculate_distances.py:66-112) of line k (frequency nl) for this v-packet
     auto d_line_of = [&](int k, double nl) -> double {
         if (FULL) {
@@ -478,7 +479,7 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
             const int w0 = max(e - 1, start + 1);
             // (two 16-byte loads: the list ends in slack, and an index clamped to the last line does not look at its frequency)
             typedef double nu2 __attribute__((ext_vector_type(2), aligned(8)));
-            const nu2 wa = *reinterpret_cast<const nu2 *>(P.nu_line + (unsigned)w0), wb = *reinterpret_cast<const nu2 *>(P.nu_line + (unsigned)w0 + 2);
+            const nu2 wa = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)w0), wb = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)w0 + 2);
             const double wn[4] = {wa.x, wa.y, wb.x, wb.y};
             bool sw[4];
 #pragma unroll
@@ -493,13 +494,13 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
             else e = min(w0 + 3, L - 1);  // beyond the window
             if (!resolved) {  // the bucket guess was further off: the reference's walk, forward then backward
                 for (;;) {
-                    d_line = d_line_of(e, P.nu_line[(unsigned)e]);
+                    d_line = d_line_of(e, nu_line_g[(unsigned)e]);
                     if (d_boundary <= d_line || e == L - 1) break;
                     ++e;
                 }
                 stops = d_boundary <= d_line;
                 while (e > start + 1) {
-                    if (!(d_boundary <= d_line_of(e - 1, P.nu_line[(unsigned)(e - 1)]))) break;
+                    if (!(d_boundary <= d_line_of(e - 1, nu_line_g[(unsigned)(e - 1)]))) break;
                     --e;
                     stops = true;
                 }
@@ -519,7 +520,7 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
         for (int k = 0; k < 8; k += 2) {
             const int o = base + k;
             const tau2 z = {0.0, 0.0};
-            const tau2 w = (o < n_sum) ? *reinterpret_cast<const tau2 *>(trow + o) : z;
+            const tau2 w = (o < n_sum) ? *reinterpret_cast<const MC_G tau2 *>(trow + o) : z;
             tv[k] = w.x; tv[k + 1] = (o + 1 < n_sum) ? w.y : 0.0;
         }
 #pragma unroll
@@ -560,8 +561,9 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
     int status = ST_IN_PROCESS;
     const int start = v.next_line;
     const int start_c = min(start, L - 1);
-    const double *__restrict__ prow = P.tau_pfx + (size_t)v.shell * (size_t)(L + 1);
-    const double nl_start = P.nu_line[(unsigned)start_c];
+    const MC_G double *__restrict__ prow = glob(P.tau_pfx) + (size_t)v.shell * (size_t)(L + 1);
+    const MC_G double *__restrict__ nu_line_g = glob(P.nu_line);
+    const double nl_start = nu_line_g[(unsigned)start_c];
     const double p_start = prow[(unsigned)min(start, L)];
     double d_boundary;
     int delta;
@@ -575,7 +577,7 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
     const double nu_thr = comov_nu - d_boundary * P.rcp_tc * v.nu;
     long long kk_b = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
     kk_b = kk_b < 0 ? 0 : (kk_b >= P.bucket_n ? P.bucket_n - 1 : kk_b);
-    const int bucket_e = P.bucket_first[kk_b];
+    const int bucket_e = glob(P.bucket_first)[kk_b];
     auto d_line_of = [&](int k, double nl) -> double {
         if (FULL) {
             double d;
@@ -598,8 +600,8 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
             if (e > L - 1) e = L - 1;
             const int w0 = max(e - 1, start + 1);
             typedef double dbl2 __attribute__((ext_vector_type(2), aligned(8)));
-            const dbl2 wa = *reinterpret_cast<const dbl2 *>(P.nu_line + (unsigned)w0), wb = *reinterpret_cast<const dbl2 *>(P.nu_line + (unsigned)w0 + 2);
-            const dbl2 pa = *reinterpret_cast<const dbl2 *>(prow + (unsigned)w0), pb = *reinterpret_cast<const dbl2 *>(prow + (unsigned)w0 + 2);
+            const dbl2 wa = *reinterpret_cast<const MC_G dbl2 *>(nu_line_g + (unsigned)w0), wb = *reinterpret_cast<const MC_G dbl2 *>(nu_line_g + (unsigned)w0 + 2);
+            const dbl2 pa = *reinterpret_cast<const MC_G dbl2 *>(prow + (unsigned)w0), pb = *reinterpret_cast<const MC_G dbl2 *>(prow + (unsigned)w0 + 2);
             const double wn[4] = {wa.x, wa.y, wb.x, wb.y}, wp[4] = {pa.x, pa.y, pb.x, pb.y};
             bool sw[4];
 #pragma unroll
@@ -618,13 +620,13 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
             } else {  // the bucket guess was further off: the reference's walk, forward then backward
                 e = sw[0] ? w0 : min(w0 + 3, L - 1);
                 for (;;) {
-                    d_line = d_line_of(e, P.nu_line[(unsigned)e]);
+                    d_line = d_line_of(e, nu_line_g[(unsigned)e]);
                     if (d_boundary <= d_line || e == L - 1) break;
                     ++e;
                 }
                 bool stops = d_boundary <= d_line;
                 while (e > start + 1) {
-                    if (!(d_boundary <= d_line_of(e - 1, P.nu_line[(unsigned)(e - 1)]))) break;
+                    if (!(d_boundary <= d_line_of(e - 1, nu_line_g[(unsigned)(e - 1)]))) break;
                     --e;
                     stops = true;
                 }
@@ -669,13 +671,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     double *lds_nubar = lds_J + H.n_shells;
     double *lds_geo = lds_nubar + H.n_shells;  // r_inner | r_outer | n_e
     for (int s = threadIdx.x; s < H.n_shells; s += 64) {
-        lds_geo[s] = W->P.r_inner[s]; lds_geo[H.n_shells + s] = W->P.r_outer[s]; lds_geo[2 * H.n_shells + s] = W->P.n_e[s];
-        if (VPK) lds_geo[3 * H.n_shells + s] = W->P.tau_rowsum ? W->P.tau_rowsum[s] : 0.0;
+        lds_geo[s] = glob(W->P.r_inner)[s]; lds_geo[H.n_shells + s] = glob(W->P.r_outer)[s]; lds_geo[2 * H.n_shells + s] = glob(W->P.n_e)[s];
+        if (VPK) lds_geo[3 * H.n_shells + s] = W->P.tau_rowsum ? glob(W->P.tau_rowsum)[s] : 0.0;
     }
     const int lane = threadIdx.x;  // one wave per workgroup
     {   // (volley queue: a wave keeps its partial sums from launch to launch and adds them to the estimators when it is done)
         const double *js = (W->resume && W->vq_jsave) ? W->vq_jsave + (size_t)blockIdx.x * (size_t)(2 * H.n_shells) : nullptr;
-        for (int s = lane; s < 2 * H.n_shells; s += 64) lds_J[s] = js ? js[s] : 0.0;
+        for (int s = lane; s < 2 * H.n_shells; s += 64) lds_J[s] = js ? glob(js)[s] : 0.0;
     }
 
     const int j = lane & (G - 1);
@@ -731,7 +733,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     // doubles of a packet; the regenerated words go to the packet's state buffer, from which later blocks read them.
     auto refill = [&](unsigned long long need, uint32_t *seeded_states) {
         if (!((need >> lane) & 1ull)) return;
-        uint32_t *st = seeded_states + ((size_t)blockIdx.x * 64 + (size_t)lane) * WV_STATE_STRIDE;  // (one state buffer per lane of the grid)
+        MC_G uint32_t *st = glob(seeded_states) + ((size_t)blockIdx.x * 64 + (size_t)lane) * WV_STATE_STRIDE;  // (one state buffer per lane of the grid)
         const int k0 = r_gpos & 0x3ff;
         uint32_t wa[9], wc[8];
         // (the state words a block needs are contiguous -- mt[k0 .. k0+8] and mt[k0+397 .. k0+404] mod 624 -- except for the one
@@ -743,7 +745,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         const bool c_contig = cb + 8 <= MT_N;
         auto load_c = [&]() {  // wc[0..7] = regenerated words mt[(k0 + 397 + i) mod 624]
             if (c_contig) {
-                const v4u lo = *reinterpret_cast<const v4u_a4 *>(st + cb), hi = *reinterpret_cast<const v4u_a4 *>(st + cb + 4);
+                const v4u lo = *reinterpret_cast<const MC_G v4u_a4 *>(st + cb), hi = *reinterpret_cast<const MC_G v4u_a4 *>(st + cb + 4);
                 wc[0] = lo.x; wc[1] = lo.y; wc[2] = lo.z; wc[3] = lo.w; wc[4] = hi.x; wc[5] = hi.y; wc[6] = hi.z; wc[7] = hi.w;
             } else {
 #pragma unroll
@@ -777,7 +779,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 for (int i = 0; i < 8; ++i) wc[i] = wi[i];
             }
         } else {
-            const v4u lo = *reinterpret_cast<const v4u *>(st + k0), hi = *reinterpret_cast<const v4u *>(st + k0 + 4);  // 32-byte aligned
+            const v4u lo = *reinterpret_cast<const MC_G v4u *>(st + k0), hi = *reinterpret_cast<const MC_G v4u *>(st + k0 + 4);  // 32-byte aligned
             wa[0] = lo.x; wa[1] = lo.y; wa[2] = lo.z; wa[3] = lo.w; wa[4] = hi.x; wa[5] = hi.y; wa[6] = hi.z; wa[7] = hi.w;
             wa[8] = st[(k0 + 8 == MT_N) ? 0 : k0 + 8];
             load_c();
@@ -788,7 +790,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             const uint32_t y = (wa[i] & 0x80000000u) | (wa[i + 1] & 0x7fffffffu);
             v[i] = wc[i] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         }
-        v4u *dst = reinterpret_cast<v4u *>(st + k0);  // 32-byte aligned: k0 is a multiple of 8
+        MC_G v4u *dst = reinterpret_cast<MC_G v4u *>(st + k0);  // 32-byte aligned: k0 is a multiple of 8
         v4u lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
         dst[0] = lo4; dst[1] = hi4;
         const int tail = (r_head + r_cnt) & (RING - 1);
@@ -799,12 +801,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     };
 
     if (W->resume) {  // continue where the previous epoch suspended this wave
-        const WaveSave ws = W->wsave[blockIdx.x];
+        // (the index is made opaque so that these stay VECTOR loads: as scalar loads -- uniform address, provably global memory --
+        // the wave-uniform bookkeeping below lands in SGPRs for the whole kernel and the register allocation of the event loop
+        // falls apart: 45 -> 215 spilled VGPRs)
+        unsigned wave_idx = blockIdx.x;
+        asm volatile("" : "+v"(wave_idx));
+        const WaveSave ws = gload(W->wsave + wave_idx);
         res_next = ws.res_next; res_end = ws.res_end; exhausted = ws.exhausted != 0;
-        if (W->log_continue) log_used = W->log.region_count[blockIdx.x];  // (volley queue: many short launches share one log buffer)
+        if (W->log_continue) log_used = glob(W->log.region_count)[wave_idx];  // (volley queue: many short launches share one log buffer)
         if (ws.done) state = WS_DONE;
         else {
-            const LaneSave &v = W->save[(size_t)blockIdx.x * 64 + lane];
+            const MC_G LaneSave &v = *glob(W->save + ((size_t)blockIdx.x * 64 + lane));  // (field by field: 360 bytes at once would not fit the registers)
             p.r = v.r; p.mu = v.mu; p.nu = v.nu; p.energy = v.energy; dop = v.dop;
             s_tau = v.s_tau; s_tau_event = v.s_tau_event; s_kp = v.s_kp; s_xb = v.s_xb;
             sh.d_cont0[lane] = v.d_cont0; sh.d_boundary[lane] = v.d_boundary;
@@ -813,7 +820,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             p.shell = v.shell; p.next_line_id = v.next_line; p.status = v.status; state = v.state; pkt = v.pkt; pflags = v.pflags;
             r_gpos = v.r_gpos; r_head = v.r_head; r_cnt = v.r_cnt;
             trk_count = v.trk_count; trk_boundary = v.trk_boundary;
-            trk_any = (v.flags & 1) != 0; s_active = (v.flags & 2) != 0; s_fast = (v.flags & 4) != 0;
+            { const int fl = v.flags; trk_any = (fl & 1) != 0; s_active = (fl & 2) != 0; s_fast = (fl & 4) != 0; }
             s_line = v.s_line; s_row = v.s_row;
             sh.res_info[lane] = v.res_info; sh.res_line[lane] = v.res_line; pre_blk = make_int2(v.pre_blk_x, v.pre_blk_y);
             sh.rng_a[lane] = v.rng_a; sh.rng_b[lane] = v.rng_b;
@@ -860,7 +867,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             // requested volley round, or done) and leave the rest to the next epoch
             suspended_log = log_full;
             suspended_drain = drain_stop && !log_full && !vq_stop;
-            LaneSave v;
+            MC_G LaneSave &v = *glob(W->save + ((size_t)blockIdx.x * 64 + lane));
             v.r = p.r; v.mu = p.mu; v.nu = p.nu; v.energy = p.energy; v.dop = dop;
             v.s_tau = s_tau; v.s_tau_event = s_tau_event; v.s_kp = s_kp; v.s_xb = s_xb;
             v.d_cont0 = sh.d_cont0[lane]; v.d_boundary = sh.d_boundary[lane];
@@ -876,7 +883,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             v.vseq = vseq; v.pred_bits = pred_bits; v.vdone = vq_done; v.pad_v0 = v.pad_v1 = v.pad_v2 = 0;
             v.walk_inv_new = sh.chi[lane]; v.walk_block = sh.rcp_chi[lane];
             v.trk_nu = sh.nu[lane]; v.trk_mu = sh.rcp_nu[lane]; v.trk_energy = sh.comov_nu[lane];
-            W->save[(size_t)blockIdx.x * 64 + lane] = v;
             suspended = true;
             break;
         }
@@ -927,13 +933,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     rec.n = (unsigned)n_visit;
                     if (my < log.region_capacity) {
                         const size_t slot = (size_t)blockIdx.x * log.region_capacity + my;
-                        log.records[slot] = rec;
-                        log.keys[slot] = (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE);
+                        gstore(log.records + slot, rec);
+                        glob(log.keys)[slot] = (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE);
                     } else {  // region full (or no log): add the terms directly (slow path)
                         for (int k = 0; k < n_visit; ++k) {
-                            const double f = FULL ? 1.0 : P.nu_line[(unsigned)(start + k)];
-                            atomic_add_f64(&jb[rec.idx0 + (unsigned)k], rec.c_jb * f);
-                            atomic_add_f64(&ed[rec.idx0 + (unsigned)k], rec.c_e * f);
+                            const double f = FULL ? 1.0 : glob(P.nu_line)[(unsigned)(start + k)];
+                            gatomic_add_f64(&jb[rec.idx0 + (unsigned)k], rec.c_jb * f);
+                            gatomic_add_f64(&ed[rec.idx0 + (unsigned)k], rec.c_e * f);
                         }
                     }
                 }
@@ -980,7 +986,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (type == IT_LINE) {
                     emit = p.next_line_id;
                     if (P.line_interaction_type != 0) {
-                        const int2 blk = LS ? pre_blk : P.line_block[(unsigned)p.next_line_id];
+                        const int2 blk = LS ? pre_blk : gload(P.line_block + (unsigned)p.next_line_id);
                         mb0 = blk.x; mb1 = blk.y;
                         in_macro = true;
                     }
@@ -1012,7 +1018,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 double event = 0.0;
                 unsigned x = 0;
                 int q_lo = 0, q_hi = 0;
-                const unsigned short *__restrict__ blk = P.cum16 + ((size_t)p.shell * P.cum16_stride + (unsigned)mb0);
+                const MC_G unsigned short *__restrict__ blk = glob(P.cum16) + ((size_t)p.shell * P.cum16_stride + (unsigned)mb0);
                 if (in_macro) {
                     event = draw();
                     x = (unsigned)(event * 65536.0);  // floor: event is in [0, 1)
@@ -1032,12 +1038,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (in_macro) {
                     const int n_quads = (mb1 + 7) >> 3;
                     const int nq = min(WALK_WINDOW_QUADS, n_quads - q_lo);
-                    const uint4 *__restrict__ wp = reinterpret_cast<const uint4 *>(blk + 8 * q_lo);
+                    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                    const MC_G u4v *__restrict__ wp = reinterpret_cast<const MC_G u4v *>(blk + 8 * q_lo);
                     uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
-                    if (nq > 0) w0 = wp[0];
-                    if (nq > 1) w1 = wp[1];
-                    if (nq > 2) w2 = wp[2];
-                    if (nq > 3) w3 = wp[3];
+                    if (nq > 0) { const u4v t = wp[0]; w0 = make_uint4(t.x, t.y, t.z, t.w); }
+                    if (nq > 1) { const u4v t = wp[1]; w1 = make_uint4(t.x, t.y, t.z, t.w); }
+                    if (nq > 2) { const u4v t = wp[2]; w2 = make_uint4(t.x, t.y, t.z, t.w); }
+                    if (nq > 3) { const u4v t = wp[3]; w3 = make_uint4(t.x, t.y, t.z, t.w); }
                     const unsigned xx = x | (x << 16);
                     unsigned less = 0, gt = 0;
                     if (nq > 0) walk_count_quad(w0, xx, less, gt);
@@ -1050,11 +1057,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         exact = true;
                         // entries equal to x (2^-16 of the draws per entry; the 0xffff padding when x = 65535): the reference's
                         // own comparison on the fp64 running sums, in order
-                        const double *__restrict__ cum = P.cum_t + (size_t)p.shell * (size_t)P.n_trans;
+                        const MC_G double *__restrict__ cum = glob(P.cum_t) + (size_t)p.shell * (size_t)P.n_trans;
                         for (; k < mb1; ++k) {
                             const unsigned v = blk[k];
                             if (v > x) break;
-                            const int2 qi = P.quad_info[(unsigned)(mb0 + k) >> 3];
+                            const int2 qi = gload(P.quad_info + ((unsigned)(mb0 + k) >> 3));
                             if (cum[(unsigned)(qi.x + (k & 7))] > event) break;
                         }
                     }
@@ -1065,7 +1072,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (in_macro) {
                     if (sel < 0) { err = ERR_MACRO_ATOM; in_macro = false; }
                     else {
-                        const WalkRec rec = P.rec16[(unsigned)(mb0 + sel)];
+                        const WalkRec rec = gload(P.rec16 + (unsigned)(mb0 + sel));
                         if (rec.b & WALK_EMIT) {
                             emit = (int)rec.a;
                             emit_nu_walk = rec.nu;  // (the emission line's frequency travels with the record: no read of nu_line afterwards)
@@ -1115,7 +1122,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (lane / G < n_items) {
                     item_of(lane / G, n_o, n_row, n_b0, n_b1, n_event);
                     const int kk = n_b0 + j;
-                    if (kk < n_b1) { n_pr = P.cum_t[n_row + (unsigned)kk]; n_rec = P.trans_rec[(unsigned)kk]; }
+                    if (kk < n_b1) { n_pr = glob(P.cum_t)[n_row + (unsigned)kk]; n_rec = gload(P.trans_rec + (unsigned)kk); }
                 }
                 for (int base = 0; base < n_items; base += 64 / G) {
                     const int o = n_o, b0 = n_b0, b1 = n_b1;
@@ -1129,7 +1136,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     if (base + 64 / G + lane / G < n_items) {
                         item_of(base + 64 / G + lane / G, n_o, n_row, n_b0, n_b1, n_event);
                         const int kk = n_b0 + j;
-                        if (kk < n_b1) { n_pr = P.cum_t[n_row + (unsigned)kk]; n_rec = P.trans_rec[(unsigned)kk]; }
+                        if (kk < n_b1) { n_pr = glob(P.cum_t)[n_row + (unsigned)kk]; n_rec = gload(P.trans_rec + (unsigned)kk); }
                     }
                     if (have) {
                         int cnt = 0;
@@ -1139,8 +1146,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             const int kk = b + j;
                             const bool in = kk < b1;
                             if (b != b0) {
-                                pr = in ? P.cum_t[row + (unsigned)kk] : 0.0;
-                                rec = in ? P.trans_rec[(unsigned)kk] : make_int4(0, 0, 0, 0);
+                                pr = in ? glob(P.cum_t)[row + (unsigned)kk] : 0.0;
+                                rec = in ? gload(P.trans_rec + (unsigned)kk) : make_int4(0, 0, 0, 0);
                             }
                             const double acc = pr;  // the block's running sum up to this entry (cum_t): nothing to scan
                             const unsigned hit = (unsigned)((__ballot(in && acc > event) >> gshift) & GMASK);
@@ -1190,13 +1197,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             while (__ballot(in_macro)) {
                 refill(__ballot(in_macro && !searching && r_cnt < 1), seeded_states);
                 if (in_macro) {
-                    const double *__restrict__ cum = P.cum_t + (unsigned)p.shell * (unsigned)P.n_trans;
+                    const MC_G double *__restrict__ cum = glob(P.cum_t) + (unsigned)p.shell * (unsigned)P.n_trans;
                     int k = -2;  // >= 0: the jump goes to transition k; -1: no entry exceeds the number drawn; -2: search on
                     if (!searching) {
                         // the first eight running sums of the block in one round trip (the table carries eight entries of
                         // slack, entries past the end of the block are ignored)
                         event = draw();
-                        const double *__restrict__ c8 = cum + (unsigned)mb0;
+                        const MC_G double *__restrict__ c8 = cum + (unsigned)mb0;
                         double a8[8];
 #pragma unroll
                         for (int q = 0; q < 8; ++q) a8[q] = c8[q];
@@ -1218,8 +1225,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     if (k == -1) { macro += (unsigned)(mb1 - mb0); err = ERR_MACRO_ATOM; in_macro = false; }
                     else if (k >= 0) {
                         macro += (unsigned)(k - mb0 + 1);
-                        const int4 rec = P.trans_rec[(unsigned)k];
-                        emit_nu = P.trans_nu[(unsigned)k]; have_emit_nu = true;
+                        const int4 rec = gload(P.trans_rec + (unsigned)k);
+                        emit_nu = glob(P.trans_nu)[(unsigned)k]; have_emit_nu = true;
                         emit = rec.x; mb0 = rec.z; mb1 = rec.w;
                         if (rec.y < 0) {
                             in_macro = false;
@@ -1236,7 +1243,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 int emit_id = -1;
                 const int absorb_id = (type == IT_LINE) ? p.next_line_id : -1;  // (the line that absorbed the packet)
                 if (type == IT_LINE) {  // line_emission (interaction_events.py:227-258); its inverse Doppler factor == inv_new
-                    p.nu = (have_emit_nu ? emit_nu : P.nu_line[emit]) * inv_new;
+                    p.nu = (have_emit_nu ? emit_nu : glob(P.nu_line)[emit]) * inv_new;
                     p.next_line_id = emit + 1;
                     emit_id = emit;
                 }
@@ -1250,7 +1257,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     rec.radius = p.r; rec.after_mu = p.mu;
                     rec.shell = p.shell; rec.type = type; rec.absorb = absorb_id; rec.emit = emit_id;
                     rec.count = trk_count; rec.valid = 1;
-                    reinterpret_cast<TrackerRecord *>(W->D.li_rec)[chunk_first + pkt] = rec;
+                    gstore(reinterpret_cast<TrackerRecord *>(W->D.li_rec) + (chunk_first + pkt), rec);
                 }
             }
             state = WS_NEED_TRACE;
@@ -1260,18 +1267,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 const long long i = chunk_first + pkt;
                 const DeviceProblem *C = &W->D;
                 if (err) {
-                    atomicMin(&C->first_error[0], i);
-                    C->out_nu[i] = (double)err;
-                    C->out_e[i] = -99.0;
+                    gatomic_min_i64(&C->first_error[0], i);
+                    glob(C->out_nu)[i] = (double)err;
+                    glob(C->out_e)[i] = -99.0;
                 } else {
                     // set_packet_collection_output (modes/montecarlo_transport.py:70-90)
-                    C->out_nu[i] = p.nu;
-                    C->out_e[i] = (p.status == ST_REABSORBED) ? -p.energy : p.energy;
+                    glob(C->out_nu)[i] = p.nu;
+                    glob(C->out_e)[i] = (p.status == ST_REABSORBED) ? -p.energy : p.energy;
                     if (TRACK && !trk_any) {  // no interaction at all: an empty record (the unpacking fills in NaN / -1 / 0)
                         TrackerRecord rec;
                         rec.before_nu = rec.before_mu = rec.before_energy = rec.radius = rec.after_mu = 0.0;
                         rec.shell = rec.type = rec.absorb = rec.emit = -1; rec.count = 0; rec.valid = 0;
-                        reinterpret_cast<TrackerRecord *>(C->li_rec)[i] = rec;
+                        gstore(reinterpret_cast<TrackerRecord *>(C->li_rec) + i, rec);
                     }
                 }
                 state = WS_NEED_PACKET;
@@ -1293,7 +1300,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (n_new > 0 && !exhausted) {
                     const int n_res = max(WV_RESERVE, n_new);
                     unsigned long long b = 0;
-                    if (lane == 0) b = atomicAdd(P.next_packet, (unsigned long long)n_res);
+                    if (lane == 0) b = gatomic_add_u64(P.next_packet, (unsigned long long)n_res);
                     const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b);
                     const unsigned bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
                     const long long got = (long long)(((unsigned long long)bhi << 32) | blo);
@@ -1309,7 +1316,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     else {
                         pkt = (int)mine;
                         r_gpos = r_head = r_cnt = 0;
-                        const LaunchRec lr = W->launch[mine];
+                        const MC_G LaunchRec &lr = *glob(W->launch + mine);
                         sh.rng_a[lane] = lr.seed;        // mt[0]
                         sh.rng_b[lane] = lr.checkpoint;  // mt[397]
                         p.r = lr.r; p.mu = lr.mu; p.nu = lr.nu; p.energy = lr.energy;
@@ -1339,7 +1346,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 int n_ok = 0, consumed = 0;
                 unsigned obs = 0;
                 for (int sl = 0; sl < n_round; ++sl) {
-                    const VpResult r = res[sl];
+                    const VpResult r = gload(res + sl);
                     vtraced_total += (unsigned)r.visits;
                     if (r.used > 0) obs |= 1u << sl;  // learn from every trace of the round, committed or not
                     if (valid) {
@@ -1350,13 +1357,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             // add_vpacket_collection_to_histogram (modes/montecarlo_transport.py:166-195)
                             if (!(r.nu < P.grid0 || r.nu > P.grid_last) && r.energy != 0.0) {  // (a dropped v-packet adds 0.0: the bin keeps its bits)
                                 const long long idx = (long long)floor((r.nu - P.grid0) / P.delta_nu);
-                                atomic_add_f64(&P.vhist[idx], r.energy);
+                                gatomic_add_f64(&P.vhist[idx], r.energy);
                             }
                             if (C->vlog_count) {
-                                const unsigned long long slot = atomicAdd(C->vlog_count, 1ull);
+                                const unsigned long long slot = gatomic_add_u64(C->vlog_count, 1ull);
                                 if ((long long)slot < C->vlog_capacity) {
-                                    C->vlog_packet[slot] = chunk_first + pkt; C->vlog_seq[slot] = vseq;
-                                    C->vlog_nu[slot] = r.nu; C->vlog_energy[slot] = r.energy; C->vlog_mu[slot] = r.mu0; C->vlog_r[slot] = p.r;
+                                    glob(C->vlog_packet)[slot] = chunk_first + pkt; glob(C->vlog_seq)[slot] = vseq;
+                                    glob(C->vlog_nu)[slot] = r.nu; glob(C->vlog_energy)[slot] = r.energy; glob(C->vlog_mu)[slot] = r.mu0; glob(C->vlog_r)[slot] = p.r;
                                 }
                             }
                             ++vseq;
@@ -1386,7 +1393,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             double mu_min = 0.0, beta_inner = 0.0, mu_bin = 0.0, r_dop = 1.0;
             bool on_inner = false;
             if (in_volley) {
-                const double r_in0 = P.r_inner[0];
+                const double r_in0 = lds_geo[0];
                 if (p.r > r_in0) {
                     const double r_inner_over_r = r_in0 / p.r;
                     mu_min = -sqrt(1 - r_inner_over_r * r_inner_over_r);
@@ -1429,7 +1436,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 const int n_items = __shfl(incl, 63);
                 if (n_items > 0) {
                     unsigned base = 0;
-                    if (lane == 0) base = atomicAdd(W->vq_count, (unsigned)n_items);
+                    if (lane == 0) base = gatomic_add_u32(W->vq_count, (unsigned)n_items);
                     base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
                     if (ask) {
                         VolleyRequest rq;
@@ -1438,8 +1445,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         rq.pred_bits = pred_bits; rq.pad0 = rq.pad1 = rq.pad2 = 0;
 #pragma unroll
                         for (int q = 0; q < WV_RING_VPK; ++q) rq.draws[q] = ring[((r_head + q) & (RING - 1)) * 64 + lane];
-                        W->vq_req[slot] = rq;
-                        unsigned *it = W->vq_items + (base + (unsigned)(incl - n_round));
+                        gstore(W->vq_req + slot, rq);
+                        MC_G unsigned *it = glob(W->vq_items) + (base + (unsigned)(incl - n_round));
                         for (int sl = 0; sl < n_round; ++sl) it[sl] = ((unsigned)slot << 3) | (unsigned)sl;
                         state = WS_VOLLEY;
                         vq_fresh = true;
@@ -1546,7 +1553,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             VpResult r;
                             r.nu = vs.nu; r.energy = st == 1 ? vs.energy * mcm::exp(-vs.tau) : 0.0; r.mu0 = vs.mu0;
                             r.used = w_used; r.visits = (int)my_visits; r.err = st < 0 ? st : 0; r.pad = 0;
-                            vres[w_item] = r;
+                            gstore(vres + w_item, r);
                             tracing = false;
                         }
                     }
@@ -1562,9 +1569,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             }
             if (verr) {  // the reference raises: the packet ends with the error code
                 const long long i = chunk_first + pkt;
-                atomicMin(&C->first_error[0], i);
-                C->out_nu[i] = (double)verr;
-                C->out_e[i] = -99.0;
+                gatomic_min_i64(&C->first_error[0], i);
+                glob(C->out_nu)[i] = (double)verr;
+                glob(C->out_e)[i] = -99.0;
                 state = WS_NEED_PACKET;
             }
         }
@@ -1742,17 +1749,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         TMC_SEC(6)
     }
 
-    if (lane == 0 && W->log.region_capacity > 0) W->log.region_count[blockIdx.x] = min(log_used, W->log.region_capacity);
+    if (lane == 0 && W->log.region_capacity > 0) glob(W->log.region_count)[blockIdx.x] = min(log_used, W->log.region_capacity);
     const DeviceProblem *C = &W->D;
     const bool keep = suspended && W->vq_jsave != nullptr;  // volley queue: partial sums and counters stay with the wave
     if (W->vq_jsave) {
         double *js = W->vq_jsave + (size_t)blockIdx.x * (size_t)(2 * H.n_shells);
-        for (int s = lane; s < 2 * H.n_shells; s += 64) js[s] = keep ? lds_J[s] : 0.0;
+        for (int s = lane; s < 2 * H.n_shells; s += 64) glob(js)[s] = keep ? lds_J[s] : 0.0;
     }
     if (!keep)
         for (int s = lane; s < H.n_shells; s += 64) {
-            if (lds_J[s] != 0.0) atomic_add_f64(&C->J[s], lds_J[s]);
-            if (lds_nubar[s] != 0.0) atomic_add_f64(&C->nubar[s], lds_nubar[s]);
+            if (lds_J[s] != 0.0) gatomic_add_f64(&C->J[s], lds_J[s]);
+            if (lds_nubar[s] != 0.0) gatomic_add_f64(&C->nubar[s], lds_nubar[s]);
         }
     // counters: wave-reduce, one atomic each
     unsigned long long v = (LS || j == 0) ? visits : 0ull;  // group sweeps: group-uniform, count once per group
@@ -1767,40 +1774,40 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             WaveSave ws;
             ws.res_next = res_next; ws.res_end = res_end; ws.exhausted = exhausted ? 1 : 0; ws.done = suspended ? 0 : 1;
             if (W->vq_jsave && W->resume) {
-                const WaveSave &old = W->wsave[blockIdx.x];
+                const WaveSave old = gload(W->wsave + blockIdx.x);
 #pragma unroll
                 for (int k = 0; k < 7; ++k) cn[k] += old.cnt[k];
             }
 #pragma unroll
             for (int k = 0; k < 7; ++k) ws.cnt[k] = keep ? cn[k] : 0ull;
-            W->wsave[blockIdx.x] = ws;
-            if (suspended) atomicAdd(W->suspended, 1u);
-            if (suspended_log) atomicAdd(W->suspended + 1, 1u);
-            if (suspended_drain) atomicAdd(W->suspended + 2, 1u);
+            gstore(W->wsave + blockIdx.x, ws);
+            if (suspended) gatomic_add_u32(W->suspended, 1u);
+            if (suspended_log) gatomic_add_u32(W->suspended + 1, 1u);
+            if (suspended_drain) gatomic_add_u32(W->suspended + 2, 1u);
         }
         if (!keep) {
-            if (cn[0]) atomicAdd(&C->counters[0], cn[0]);
-            if (cn[1]) atomicAdd(&C->counters[1], cn[1]);
-            if (cn[2]) atomicAdd(&C->counters[2], cn[2]);
-            if (cn[3]) atomicAdd(&C->counters[5], cn[3]);
+            if (cn[0]) gatomic_add_u64(&C->counters[0], cn[0]);
+            if (cn[1]) gatomic_add_u64(&C->counters[1], cn[1]);
+            if (cn[2]) gatomic_add_u64(&C->counters[2], cn[2]);
+            if (cn[3]) gatomic_add_u64(&C->counters[5], cn[3]);
             if (VPK) {
-                if (cn[4]) atomicAdd(&C->counters[3], cn[4]);
-                if (cn[5]) atomicAdd(&C->counters[4], cn[5]);
-                if (cn[6]) atomicAdd(&C->counters[7], cn[6]);
+                if (cn[4]) gatomic_add_u64(&C->counters[3], cn[4]);
+                if (cn[5]) gatomic_add_u64(&C->counters[4], cn[5]);
+                if (cn[6]) gatomic_add_u64(&C->counters[7], cn[6]);
             }
         }
-        if (H.debug_flags & 16) atomicAdd(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
-        if (H.debug_flags & (16384 | 32768)) atomicAdd(&C->counters[7], (unsigned long long)dbg_walk);  // tests only
-        if (H.debug_flags & 2097152) atomicAdd(&C->counters[7], dbg_drain_t0 ? wall_clock64() - dbg_drain_t0 : 0ull);
-        if (H.debug_flags & 4194304) atomicAdd(&C->counters[7], (unsigned long long)dbg_drain_passes);
-        if (H.debug_flags & 8388608) atomicAdd(&C->counters[7], (unsigned long long)dbg_drain_lanes);
-        if (H.debug_flags & 32) atomicAdd(&C->counters[7], (unsigned long long)dbg_passes);
+        if (H.debug_flags & 16) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
+        if (H.debug_flags & (16384 | 32768)) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_walk);  // tests only
+        if (H.debug_flags & 2097152) gatomic_add_u64(&C->counters[7], dbg_drain_t0 ? wall_clock64() - dbg_drain_t0 : 0ull);
+        if (H.debug_flags & 4194304) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_drain_passes);
+        if (H.debug_flags & 8388608) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_drain_lanes);
+        if (H.debug_flags & 32) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_passes);
 #ifdef TMC_SECTION_TIMERS
         if (H.debug_flags & 64) {
             unsigned long long tsel = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) if (((H.debug_flags >> 8) & 7) == i) tsel = sec_t[i];
-            atomicAdd(&C->counters[7], tsel);
+            gatomic_add_u64(&C->counters[7], tsel);
         }
 #endif
     }
@@ -1819,11 +1826,11 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
     const int S = P.n_shells;
     const int lane = threadIdx.x;
     for (int s = lane; s < S; s += 64) {
-        geo[s] = P.r_inner[s]; geo[S + s] = P.r_outer[s]; geo[2 * S + s] = P.n_e[s];
-        geo[3 * S + s] = P.tau_rowsum ? P.tau_rowsum[s] : 0.0;
+        geo[s] = glob(P.r_inner)[s]; geo[S + s] = glob(P.r_outer)[s]; geo[2 * S + s] = glob(P.n_e)[s];
+        geo[3 * S + s] = P.tau_rowsum ? glob(P.tau_rowsum)[s] : 0.0;
     }
     __syncthreads();
-    const unsigned n_items = W->vq_count[0];
+    const unsigned n_items = glob(W->vq_count)[0];
     const int n_v = (int)P.n_vpackets;
     const double t = P.t_exp;
     const double r_in0 = geo[0];
@@ -1848,7 +1855,7 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
         if (free_l) {
             if (res_next == res_end && !exhausted) {
                 unsigned b = 0;
-                if (lane == 0) b = atomicAdd(W->vq_count + 1, (unsigned)VQ_RESERVE);
+                if (lane == 0) b = gatomic_add_u32(W->vq_count + 1, (unsigned)VQ_RESERVE);
                 b = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
                 if (b >= n_items) exhausted = true;
                 else { res_next = b; res_end = min(b + (unsigned)VQ_RESERVE, n_items); }
@@ -1864,9 +1871,9 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
             continue;
         }
         if (take) {
-            const unsigned it = W->vq_items[my_item];
+            const unsigned it = glob(W->vq_items)[my_item];
             my_slot = it >> 3; my_sl = (int)(it & 7u);
-            const VolleyRequest *rq = W->vq_req + my_slot;
+            const MC_G VolleyRequest *rq = glob(W->vq_req + my_slot);
             const double f_r = rq->r, f_mu = rq->mu, f_nu = rq->nu, f_energy = rq->energy;
             const int f_vdone = rq->vdone;
             const unsigned f_pred = rq->pred_bits;
@@ -1914,7 +1921,7 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
             v_margin = 0.0; v0_r = f_r; v0_energy = vs.energy; v0_shell = vs.shell; v0_line = vs.next_line;
         }
         if (tracing) {
-            const double *dr = W->vq_req[my_slot].draws;
+            const MC_G double *dr = glob(W->vq_req + my_slot)->draws;
             auto wdraw = [&]() {
                 const double d = dr[w_q + w_used];
                 ++w_used;
@@ -1934,7 +1941,7 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
                 VpResult r;
                 r.nu = vs.nu; r.energy = st == 1 ? vs.energy * mcm::exp(-vs.tau) : 0.0; r.mu0 = vs.mu0;
                 r.used = w_used; r.visits = (int)my_visits; r.err = st < 0 ? st : 0; r.pad = 0;
-                W->vp_scratch[(size_t)my_slot * VP_ROUND + my_sl] = r;
+                gstore(W->vp_scratch + ((size_t)my_slot * VP_ROUND + my_sl), r);
                 tracing = false;
             }
         }

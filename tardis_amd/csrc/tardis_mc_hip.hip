@@ -100,7 +100,7 @@ struct TardisMcContext {
     int n_lines = 0, n_trans = 0, n_levels = 0;
     DevBuf nu_line, tau_t, n_e, prob_t, cum_t, trans_nu, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec, bucket_first;
     DevBuf cum16, rec16, quad_info, line_block_c;  // compact walk tables (walk_tables.hpp)
-    DevBuf tau_pfx, tau_rowsum;                    // v-packet screening tables (tau_prefix.hpp), built at the first v-packet call after set_opacity
+    DevBuf tau_pfx, tau_rowsum, pfx_flag;          // v-packet screening tables (tau_prefix.hpp), built at the first SCREENING call after set_opacity (+ their negative-depth flag)
     bool pfx_valid = false, pfx_negative = false;
     unsigned cum16_stride = 0;
     bool have_walk_tables = false;
@@ -1172,32 +1172,33 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // shape: 1.7x - 2.1x); on the tardis_example shape (~12 lines per crossing, most v-packets leave the grid alive) the
     // screening is a second trace on top of the first: -36 % (profiles/r03_vpacket_screening.txt).  "vpacket_screening" 0 / 1
     // overrides the automatic choice.
+    // (decided from cheap predicates first: whether the tables are BUILT depends on the kernel the call ends up on -- calls that
+    // take the lane kernel (more than 32 v-packets per volley, unsorted line list, variant 0) never read them: S x (L + 1)
+    // doubles, 400 MB at the configs[4] shape, and a blocking read-back of the negative-depth flag)
     bool screen_on = false;
     {
         const bool screen_auto = (long long)ctx->n_lines >= 2500LL * (long long)ctx->n_shells;
         const bool screen = ctx->vpacket_screening < 0 ? screen_auto : ctx->vpacket_screening != 0;
-        if (vpk && c.survival_probability == 0.0 && screen && !(ctx->debug_flags & 33554432)) {
-            if (!ctx->pfx_valid) {
-                const size_t S = (size_t)ctx->n_shells, L = (size_t)ctx->n_lines;
-                HIP_TRY(ctx, ctx->tau_pfx.ensure((S * (L + 1) + 8) * sizeof(double)));  // (+8: the four-entry windows of the screening)
-                HIP_TRY(ctx, ctx->tau_rowsum.ensure(S * sizeof(double)));
-                int *flag = nullptr;
-                HIP_TRY(ctx, hipMalloc((void **)&flag, sizeof(int)));
-                hipError_t e0 = hipMemsetAsync(flag, 0, sizeof(int), ctx->stream);
-                hipLaunchKernelGGL(mc::tau_prefix_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, ctx->tau_t.as<double>(), (int)L,
-                                   ctx->tau_pfx.as<double>(), ctx->tau_rowsum.as<double>(), flag);
-                int neg = 0;
-                hipError_t e1 = hipGetLastError();
-                hipError_t e2 = hipMemcpyAsync(&neg, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-                hipError_t e3 = hipStreamSynchronize(ctx->stream);
-                (void)hipFree(flag);
-                HIP_TRY(ctx, e0); HIP_TRY(ctx, e1); HIP_TRY(ctx, e2); HIP_TRY(ctx, e3);
-                ctx->pfx_negative = neg != 0;
-                ctx->pfx_valid = true;
-            }
-            screen_on = !ctx->pfx_negative;
-        }
+        screen_on = vpk && c.survival_probability == 0.0 && screen && !(ctx->debug_flags & 33554432) &&
+                    !(ctx->pfx_valid && ctx->pfx_negative);
     }
+    auto build_screening_tables = [&]() -> int {  // first v-packet call after set_opacity that screens
+        if (ctx->pfx_valid) return TARDIS_MC_OK;
+        const size_t S = (size_t)ctx->n_shells, L = (size_t)ctx->n_lines;
+        HIP_TRY(ctx, ctx->tau_pfx.ensure((S * (L + 1) + 8) * sizeof(double)));  // (+8: the four-entry windows of the screening)
+        HIP_TRY(ctx, ctx->tau_rowsum.ensure(S * sizeof(double)));
+        HIP_TRY(ctx, ctx->pfx_flag.ensure(sizeof(int)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->pfx_flag.p, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(mc::tau_prefix_kernel, dim3((unsigned)S), dim3(256), 0, ctx->stream, ctx->tau_t.as<double>(), (int)L,
+                           ctx->tau_pfx.as<double>(), ctx->tau_rowsum.as<double>(), ctx->pfx_flag.as<int>());
+        HIP_TRY(ctx, hipGetLastError());
+        int neg = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&neg, ctx->pfx_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->pfx_negative = neg != 0;
+        ctx->pfx_valid = true;
+        return TARDIS_MC_OK;
+    };
     const bool prefer_lane_sweeps = !c.enable_full_relativity && !vpk;
     // With v-packets the wave kernel's pooled volleys win where a v-packet crosses few shells and few lines (the tardis_example
     // shape: 8.0 vs 5.2 Mpkt/s); on finer grids and longer line lists the group kernel -- every lane of a packet's group traces one
@@ -1220,6 +1221,20 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     if (ctx->prob_negative && variant == 4) variant = 1;
     const bool cooperative = ctx->lines_sorted && (variant == 1 || variant == 2 || variant == 3 || variant == 4) && (!vpk || c.number_of_vpackets <= 32);
     ctx->last_variant = cooperative ? ((variant == 3 && c.enable_full_relativity) ? 2 : variant) : 0;
+    if (screen_on && !cooperative) screen_on = false;  // (the lane kernel traces line by line)
+    if (screen_on) {
+        rc = build_screening_tables();
+        if (rc) return rc;
+        if (ctx->pfx_negative) {
+            // a negative optical depth: no screening (the prefix sums would not bound the serial sum).  The automatic kernel
+            // choice counted on it for long calls of the wave kernel: take what it picks without the screening.
+            screen_on = false;
+            if (ctx->variant < 0 && variant == 2 && vpk && !(ctx->n_shells <= 30 && ctx->n_lines <= 100000)) {
+                variant = 1;
+                ctx->last_variant = variant;
+            }
+        }
+    }
 
     if (!cooperative) {
         // variant 0: lane-per-packet, persistent-ish grid, static round-robin packet assignment

@@ -11,11 +11,16 @@ any other framework.  The same code runs on CPU (world_size-2 tests).
 
 Rendezvous on one node.  The launcher's agent already owns MASTER_PORT (its own store), so rank 0 binds an ephemeral
 port on MASTER_ADDR and publishes it in a small file named after (MASTER_PORT, the launcher's pid -- every rank is a
-child of the same agent); the other ranks poll for it.  ``TARDIS_AMD_CONTROL_PORT`` pins the port instead (ranks
-started by hand).
+child of the same agent) inside a per-user 0700 directory of the temp dir (created O_EXCL | O_NOFOLLOW, removed at exit);
+the other ranks poll for it.  ``TARDIS_AMD_CONTROL_PORT`` pins the port instead (ranks started by hand).
+
+Several nodes.  Ranks of other nodes share neither the temp dir nor the parent pid, so a multi-node launch (LOCAL_WORLD_SIZE
+!= WORLD_SIZE, or GROUP_RANK / NODE_RANK > 0) takes a fixed port: ``TARDIS_AMD_CONTROL_PORT`` if set, else MASTER_PORT + 1 on
+MASTER_ADDR (rank 0 runs on the master node in every torchrun layout).
 """
 from __future__ import annotations
 
+import atexit
 import os
 import socket
 import struct
@@ -47,8 +52,12 @@ def _recv_exact(sock: socket.socket, n: int) -> bytes:
     return bytes(buf)
 
 
-def _recv_msg(sock: socket.socket) -> bytes:
+def _recv_msg(sock: socket.socket, max_bytes: int | None = None) -> bytes:
+    """One length-prefixed message.  ``max_bytes`` bounds what an UNTRUSTED peer (anything that connects during the
+    rendezvous: a port scanner, an HTTP probe) can make this process allocate."""
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if max_bytes is not None and n > max_bytes:
+        raise ConnectionError(f"control plane: a {n}-byte message where at most {max_bytes} bytes are expected")
     return _recv_exact(sock, n) if n else b""
 
 
@@ -133,8 +142,54 @@ class ProcessGroup:
             self._rdzv_file = None
 
 
+def _rendezvous_dir() -> str:
+    """A directory only this user can write to (the temp dir itself is world-writable: a predictable file name there could
+    be pre-created, or be a symlink, by somebody else)."""
+    d = os.path.join(tempfile.gettempdir(), f"tardis_amd_ctl_{os.getuid()}")
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f"control plane: {d} is not a private directory of this user")
+    return d
+
+
 def _rendezvous_path(master_port: str) -> str:
-    return os.path.join(tempfile.gettempdir(), f"tardis_amd_ctl_{master_port}_{os.getppid()}")
+    return os.path.join(_rendezvous_dir(), f"{master_port}_{os.getppid()}")
+
+
+def _publish_port(path: str, port: int) -> None:
+    """Write the port file: never through a symlink, never over somebody else's file; stale files of an earlier job with the
+    same (MASTER_PORT, launcher pid) are this user's own (private directory) and are replaced."""
+    tmp = f"{path}.{os.getpid()}"
+    try:
+        os.unlink(tmp)
+    except OSError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    with os.fdopen(fd, "w") as f:
+        f.write(str(port))
+    os.replace(tmp, path)  # (atomic: a reader sees the old content or the new one)
+
+
+def _unlink_quietly(path: str) -> None:
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+
+
+def _multi_node() -> bool:
+    env = os.environ
+    try:
+        if int(env.get("LOCAL_WORLD_SIZE", env.get("WORLD_SIZE", "1"))) != int(env.get("WORLD_SIZE", "1")):
+            return True
+        return int(env.get("GROUP_RANK", "0")) > 0 or int(env.get("NODE_RANK", "0")) > 0 or int(env.get("NNODES", "1")) > 1
+    except ValueError:
+        return False
 
 
 def init_from_env(backend: str = "tcp") -> ProcessGroup:
@@ -148,6 +203,8 @@ def init_from_env(backend: str = "tcp") -> ProcessGroup:
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     master_port = os.environ.get("MASTER_PORT", "29533")
     fixed = os.environ.get("TARDIS_AMD_CONTROL_PORT")
+    if not fixed and _multi_node():
+        fixed = str(int(master_port) + 1)  # (no shared temp dir / parent pid across nodes: a port every rank can derive)
     token = struct.pack("<4sqq", _HELLO, int(master_port), world)
     deadline = time.monotonic() + _CONNECT_TIMEOUT_S
     if rank == 0:
@@ -158,10 +215,8 @@ def init_from_env(backend: str = "tcp") -> ProcessGroup:
         path = None
         if not fixed:
             path = _rendezvous_path(master_port)
-            tmp = f"{path}.{os.getpid()}"
-            with open(tmp, "w") as f:
-                f.write(str(srv.getsockname()[1]))
-            os.replace(tmp, path)  # (atomic: a reader sees the old content or the new one)
+            _publish_port(path, srv.getsockname()[1])
+            atexit.register(_unlink_quietly, path)  # (destroy() removes it, too; this covers a rank 0 that never gets there)
         peers: list = [None] * (world - 1)
         srv.settimeout(1.0)
         while any(p is None for p in peers):
@@ -172,10 +227,10 @@ def init_from_env(backend: str = "tcp") -> ProcessGroup:
             except socket.timeout:
                 continue
             c.settimeout(30.0)
-            try:
-                hello = _recv_msg(c)
-                r = struct.unpack("<q", hello[len(token):])[0] if hello[:len(token)] == token else -1
-            except (OSError, struct.error):
+            try:  # (whatever a stray client sends -- garbage, a huge length prefix, nothing -- only costs it its connection)
+                hello = _recv_msg(c, max_bytes=len(token) + 8)
+                r = struct.unpack("<q", hello[len(token):])[0] if len(hello) == len(token) + 8 and hello[:len(token)] == token else -1
+            except Exception:  # noqa: BLE001
                 r = -1
             if not (1 <= r < world) or peers[r - 1] is not None:
                 c.close()  # (a stray connection, or a rank of another job that read a stale file)
@@ -189,17 +244,23 @@ def init_from_env(backend: str = "tcp") -> ProcessGroup:
     while True:
         if time.monotonic() > deadline:
             raise TimeoutError("control plane: rank 0 not reachable")
+        s = None
         try:
             port = int(fixed) if fixed else int(open(_rendezvous_path(master_port)).read())
             s = socket.create_connection((addr, port), timeout=5.0)
             s.settimeout(30.0)
             _send_msg(s, token + struct.pack("<q", rank))
-            if _recv_msg(s) != token:  # (something else listens there: a stale file of an earlier job)
+            if _recv_msg(s, max_bytes=len(token)) != token:  # (something else listens there: a stale file of an earlier job)
                 raise ConnectionError("control plane: wrong peer")
             s.settimeout(None)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             return ProcessGroup(rank, world, local_rank, [], s, None)
-        except (OSError, ValueError):
+        except (OSError, ValueError, struct.error):
+            if s is not None:  # (every failed attempt gives its socket back)
+                try:
+                    s.close()
+                except OSError:
+                    pass
             time.sleep(0.05)
 
 

@@ -31,7 +31,13 @@ class Engine:
         self._vpk_log = False
         self._n_v = 0
         self.packets_generation = 0  # bumped whenever the resident packets are replaced (lazy host views check it)
-        self.results_generation = 0  # bumped by every propagate()
+        self.results_generation = 0  # bumped by every propagate() that succeeded
+        # bumped by everything that changes the resident estimators: propagate, reset_estimators, allreduce_estimators
+        # (lazy views of a resident run check it: a later reset / all-reduce must not be read as that run's estimators)
+        self.estimators_generation = 0
+        # the opacity object whose tables are in HBM (None: unknown) -- residency is a property of the ENGINE, which several
+        # solvers and the non-resident entry point may share (MCTransportSolverHIP reuses the upload only against this)
+        self.resident_opacity = None
 
     # -- lifetime
     def close(self):
@@ -79,8 +85,10 @@ class Engine:
 
     def set_opacity(self, opacity_state):
         m = _abi.marshal_opacity(opacity_state)
+        self.resident_opacity = None  # (a failed upload leaves the tables undefined)
         self._check(self._L.tardis_mc_set_opacity(self._h, m.ref()), "set_opacity")
         self.n_lines, self.n_shells = int(m.struct.n_lines), int(m.struct.n_shells)
+        self.resident_opacity = opacity_state
 
     def set_config(self, montecarlo_configuration, spectrum_frequency_grid, number_of_vpackets=None, sigma_thomson=None):
         m = _abi.marshal_config(montecarlo_configuration, spectrum_frequency_grid, number_of_vpackets, sigma_thomson)
@@ -96,11 +104,17 @@ class Engine:
         self.packets_generation += 1
 
     def reset_estimators(self):
+        self.estimators_generation += 1
         self._check(self._L.tardis_mc_reset_estimators(self._h), "reset_estimators")
 
     def propagate(self):
+        # (whatever happens, the previous run's results are gone; the counters a view compares with only become valid --
+        # equal to the view's -- for views created AFTER a successful call)
         self.results_generation += 1
+        self.estimators_generation += 1
         self._check(self._L.tardis_mc_propagate(self._h), "propagate")
+        self.results_generation += 1
+        self.estimators_generation += 1
 
     def synchronize(self):
         self._check(self._L.tardis_mc_synchronize(self._h), "synchronize")
@@ -224,6 +238,7 @@ class Engine:
         self._check(self._L.tardis_mc_comm_init(self._h, rank, world_size, buf), "comm_init")
 
     def allreduce_estimators(self):
+        self.estimators_generation += 1
         self._check(self._L.tardis_mc_allreduce_estimators(self._h), "allreduce_estimators")
 
     # -- diagnostics

@@ -181,11 +181,20 @@ class _DeviceEstimators:
     """EstimatorsLine / the last-interaction trackers of a resident run: fetched from the engine on first access."""
 
     def __init__(self, engine: Engine):
-        self._eng, self._rgen, self._line, self._trk = engine, engine.results_generation, None, None
+        self._eng, self._rgen, self._egen, self._line, self._trk = engine, engine.results_generation, engine.estimators_generation, None, None
 
-    def _fresh(self):
+    def rebase(self):
+        """The owner of the run changed the resident estimators on purpose (the N-GPU all-reduce of an outer iteration):
+        they are still this run's."""
+        self._fresh(estimators=False)
+        self._egen = self._eng.estimators_generation
+
+    def _fresh(self, estimators=True):
         if self._rgen != self._eng.results_generation:
             raise RuntimeError("the engine has propagated again since: these estimators are gone")
+        if estimators and self._egen != self._eng.estimators_generation:
+            raise RuntimeError("the engine's estimators were reset / all-reduced since this run: they are no longer this run's "
+                               "(call transport_state.estimators_allreduced() after an intended all-reduce)")
 
     def _lines(self):
         if self._line is None:
@@ -199,7 +208,7 @@ class _DeviceEstimators:
 
     def trackers(self):
         if self._trk is None:
-            self._fresh()
+            self._fresh(estimators=False)
             self._trk = self._eng.get_results(track_last_interaction=True, want_line_estimators=False, want_packet_outputs=False).trackers
         return self._trk
 
@@ -219,7 +228,8 @@ class MonteCarloTransportState:
         self.tracker_full_df = None
         self.enable_full_relativity = False
         self.virt_logging = False
-        self._engine = None           # set by a resident run: the reductions below then happen on the device
+        self._engine = None           # set by a resident run on device packets: the spectrum is then reduced on the device
+        self._est_engine = None       # set by every resident run: the engine that holds this run's estimators
         self._device_estimators = None
 
     @property
@@ -249,10 +259,16 @@ class MonteCarloTransportState:
     def radiation_field(self, volume, w_epsilon=1e-10, detailed_optical_window=False, want_j_blues=True):
         """MCRadiationFieldPropertiesSolver.solve (estimators/mc_rad_field_solver.py:37-144) on the engine's resident (after
         an N-GPU step: all-reduced) estimators.  Only after a resident run."""
-        if self._engine is None:
+        if self._est_engine is None:
             raise RuntimeError("radiation_field() needs a resident run (MCTransportSolverHIP(..., resident=True))")
         self._device_estimators._fresh()
-        return self._engine.radiation_field(self.time_of_simulation, volume, w_epsilon, detailed_optical_window, want_j_blues)
+        return self._est_engine.radiation_field(self.time_of_simulation, volume, w_epsilon, detailed_optical_window, want_j_blues)
+
+    def estimators_allreduced(self):
+        """Tell the lazy views that the engine's estimators were all-reduced on purpose after this run (N-GPU outer iteration:
+        Engine.allreduce_estimators, then radiation_field())."""
+        if self._device_estimators is not None:
+            self._device_estimators.rebase()
 
     output_nu = property(lambda self: self.packet_collection.output_nus)
     output_energy = property(lambda self: self.packet_collection.output_energies)
@@ -322,7 +338,6 @@ class MCTransportSolverHIP:
         self.enable_last_interaction_tracking = bool(enable_last_interaction_tracking)
         self.transport_state = None
         self._engine = engine          # (default: the process-wide engine of the device)
-        self._resident_opacity = None  # (engine, opacity object) whose tables are in HBM
 
     def _eng(self) -> Engine:
         return self._engine if self._engine is not None else get_engine(self.device_id)
@@ -377,10 +392,10 @@ class MCTransportSolverHIP:
         eng = self._eng()
         eng.set_geometry(ts.geometry_state_numba, float(ts.time_explosion))
         op = ts.opacity_state_numba
-        if not (self.reuse_opacity and self._resident_opacity is not None and self._resident_opacity[0] is eng
-                and self._resident_opacity[1] is op):
+        # (residency is tracked on the engine: the default engine is process-wide, and another solver or the non-resident
+        # entry point may have uploaded different tables since this solver's last run)
+        if not (self.reuse_opacity and eng.resident_opacity is op):
             eng.set_opacity(op)
-            self._resident_opacity = (eng, op)
         eng.set_config(cfg, self.spectrum_frequency_grid, cfg.NUMBER_OF_VPACKETS)
         eng.set_option("track_last_interaction", int(self.enable_last_interaction_tracking))
         pc = ts.packet_collection
@@ -399,7 +414,8 @@ class MCTransportSolverHIP:
             r = eng.get_results(pc.output_nus, pc.output_energies, track_last_interaction=False, want_line_estimators=False)
             if r.output_nus is not pc.output_nus:
                 pc.output_nus[:] = r.output_nus; pc.output_energies[:] = r.output_energies
-        ts._engine = eng if device_packets else None
+        ts._engine = eng if device_packets else None  # (host packets: the spectrum comes from the host outputs)
+        ts._est_engine = eng
         ts._device_estimators = _DeviceEstimators(eng)
         ts.estimators_bulk = st.EstimatorsBulk(res.j_estimator, res.nu_bar_estimator)
         ts.estimators_line = ts._device_estimators
