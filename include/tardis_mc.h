@@ -163,12 +163,18 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
  * "vpacket_screening" (v-packets whose Russian roulette is decided from prefix sums of tau instead of a line-by-line trace,
  * csrc/tau_prefix.hpp: -1 automatic -- on where a shell crossing passes many lines --, 0 off, 1 on),
  * "walk_sector_packing" (1, the default: blocks of the compact walk tables do not straddle 64-byte sectors; takes effect at the
- * next tardis_mc_set_opacity), "drain_split" (1: the drain of a call runs as a launch of its own beside the estimator passes of
+ * next tardis_mc_set_opacity),
+ * "walk_hot" (hot sectors of the macro-atom walk, csrc/walk_tables.hpp: one 64-byte record per (shell, block) with the block's
+ * six widest probability intervals decides most jumps out of skewed blocks in one request; -1, the default: for the blocks
+ * whose six intervals cover at least "walk_hot_min_mass" (per mille, default 800; blocks of more than 32 transitions:
+ * "walk_hot_min_mass_long", default 400) of the block on average over the shells; 0 none; 1 every block; all three take effect
+ * at the next tardis_mc_set_opacity), "drain_split" (1: the drain of a call runs as a launch of its own beside the estimator passes of
  * what was logged before it; measured, off by default),
  * "debug_flags" (profiling experiments / cross-checks only: 1 skips the j_blue/Edotlu updates, 2 the J/nu_bar updates, 128
  * walks the macro atom by a per-lane search in the fp64 running sums, 8192 by the cooperative group scan; tests: 16384 counts
  * the jumps out of blocks longer than one window of the compact walk tables into counters[7], 32768 the jumps decided by the
- * fp64 running sums because 16-bit entries tie, 67108864 the v-packets decided by the screening into counters[7] >> 40;
+ * fp64 running sums because 16-bit entries tie, 65536 / 131072 the jumps a hot sector decided / handed on to the block's own
+ * tables, 67108864 the v-packets decided by the screening into counters[7] >> 40;
  * diagnostics of a call's drain: 2097152 / 4194304 / 8388608 sum, per wave and from the pass in which its packet supply ran out,
  * the 10-ns ticks to its end / its passes / its live lanes over those passes into counters[7]; 16777216 restores the fixed
  * cut-offs of the sweep and walk phases of rounds 1-2; 33554432 switches the v-packet screening off). */

@@ -230,6 +230,12 @@ static void move_across_shell_boundary(int64_t *shell, int64_t *status, int64_t 
 }
 
 /* ------------------------------------------------------------------------------------ trace_packet -- */
+/* Analysis hook (tools/locality_stats.py; single-threaded runs only): every trace's {shell, first line, lines visited, event
+ * type} appended to a caller-owned buffer.  Not part of any parity path. */
+static int64_t *g_trace_log = NULL, g_trace_log_cap = 0, g_trace_log_n = 0;
+void oracle_set_trace_log(int64_t *buf, int64_t capacity_records) { g_trace_log = buf; g_trace_log_cap = capacity_records; g_trace_log_n = 0; }
+int64_t oracle_trace_log_count(void) { return g_trace_log_n; }
+
 static int trace_packet(const run_ctx *c, rpacket *p, mt_state *rng, double chi_cont, double *out_distance,
                         int *out_type, int64_t *out_delta, counters *cn)
 { /* homologous_rad_packet_transport.py:30-174 (continuum_process_enabled = False, escat_prob = 1) */
@@ -282,6 +288,10 @@ static int trace_packet(const run_ctx *c, rpacket *p, mt_state *rng, double chi_
     if (!broke) { /* for-else (lines 157-172): next_line_id is left untouched */
         if (d_cont < d_boundary) { distance = d_cont; type = IT_ESCATTERING; }
         else { distance = d_boundary; type = IT_BOUNDARY; }
+    }
+    if (g_trace_log && g_trace_log_n < g_trace_log_cap) {
+        int64_t *r = g_trace_log + 4 * g_trace_log_n++;
+        r[0] = p->current_shell_id; r[1] = start; r[2] = (broke ? p->next_line_id + 1 : L) - start; r[3] = type;
     }
     *out_distance = distance;
     *out_type = type;

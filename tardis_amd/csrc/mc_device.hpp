@@ -124,6 +124,9 @@ struct GroupArgs {
     const struct WalkRec *rec16;  // [compact transitions]
     const int2 *quad_info;        // [compact transitions / 8]
     unsigned cum16_stride;
+    const unsigned *hot_sec;      // [S][blocks][16]: hot sectors (null: no block is entered through one)
+    const int2 *blk_tab;          // [blocks] {compact start, rows}
+    unsigned hot_stride;          // dwords per shell of hot_sec (16 * blocks)
     double *jblue_t, *edot_t;
     long long est_copy_stride;
     unsigned long long *next_packet;

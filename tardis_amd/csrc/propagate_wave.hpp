@@ -119,6 +119,7 @@ struct __attribute__((aligned(16))) LaneSave {
     int vdone, pad_v0, pad_v1, pad_v2;  // volley queue: v-packets of the running volley committed so far (state WS_VOLLEY)
     // a carried-over macro-atom walk (state WS_WALK) and the interaction it belongs to: sh.chi | sh.rcp_chi | sh.nu | sh.rcp_nu | sh.comov_nu
     double walk_inv_new, walk_block, trk_nu, trk_mu, trk_energy;
+    double walk_event, pad_w;  // sh.tau_event: the number a carried walk looks up again (WALK_REDO)
 };
 struct WaveSave {
     long long res_next, res_end;
@@ -825,7 +826,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             sh.res_info[lane] = v.res_info; sh.res_line[lane] = v.res_line; pre_blk = make_int2(v.pre_blk_x, v.pre_blk_y);
             sh.rng_a[lane] = v.rng_a; sh.rng_b[lane] = v.rng_b;
             vseq = v.vseq; pred_bits = v.pred_bits; vq_done = v.vdone;
-            sh.chi[lane] = v.walk_inv_new; sh.rcp_chi[lane] = v.walk_block;
+            sh.chi[lane] = v.walk_inv_new; sh.rcp_chi[lane] = v.walk_block; sh.tau_event[lane] = v.walk_event;
             sh.nu[lane] = v.trk_nu; sh.rcp_nu[lane] = v.trk_mu; sh.comov_nu[lane] = v.trk_energy;
         }
     }
@@ -881,7 +882,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             v.res_info = sh.res_info[lane]; v.res_line = sh.res_line[lane]; v.pre_blk_x = pre_blk.x; v.pre_blk_y = pre_blk.y;
             v.rng_a = sh.rng_a[lane]; v.rng_b = sh.rng_b[lane];
             v.vseq = vseq; v.pred_bits = pred_bits; v.vdone = vq_done; v.pad_v0 = v.pad_v1 = v.pad_v2 = 0;
-            v.walk_inv_new = sh.chi[lane]; v.walk_block = sh.rcp_chi[lane];
+            v.walk_inv_new = sh.chi[lane]; v.walk_block = sh.rcp_chi[lane]; v.walk_event = sh.tau_event[lane]; v.pad_w = 0.0;
             v.trk_nu = sh.nu[lane]; v.trk_mu = sh.rcp_nu[lane]; v.trk_energy = sh.comov_nu[lane];
             suspended = true;
             break;
@@ -1003,7 +1004,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             // jump one 16..64-byte read of the block's 16-bit running sums (all of a block of <= 32 transitions; longer blocks
             // are first narrowed by a binary search over their 8-entry quads) and one 8-byte read of what the selected
             // transition leads to.  64 jumps of a wave are in flight at once; here mb0 / mb1 = compact start / rows of the block.
+            // A block with a hot sector (walk_tables.hpp; mb1 < 0, mb0 = block id) is entered through that sector: ONE request decides
+            // the jump and names its destination when the number drawn falls into one of the block's six widest intervals; else
+            // the same number is looked up in the block's own tables in the next round (`redo`).
             const int walk_cut = (H.debug_flags & 16777216) ? H.walk_min_active : (H.walk_min_active * __popcll(__ballot(state != WS_DONE))) >> 6;
+            bool redo = false;
+            double event = 0.0;
+            if (resumed && mb1 >= 0 && (mb1 & WALK_REDO)) { redo = true; mb1 &= ~WALK_REDO; event = sh.tau_event[lane]; }
             for (int round = 0;; ++round) {
                 const unsigned long long walking = __ballot(in_macro);
                 if (!walking) break;
@@ -1014,78 +1021,107 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 // (the cut-off is a share of the wave's LIVE lanes: in the drain of a call -- a wave with a handful of packets left --
                 // a fixed count would end the phase after every round and charge each of them a whole pass)
                 if (!VPK && round > 0 && __popcll(walking) <= walk_cut && __ballot(!in_macro && state != WS_DONE)) break;
-                refill(__ballot(in_macro && r_cnt < 1), seeded_states);
-                double event = 0.0;
+                refill(__ballot(in_macro && !redo && r_cnt < 1), seeded_states);
                 unsigned x = 0;
-                int q_lo = 0, q_hi = 0;
-                const MC_G unsigned short *__restrict__ blk = glob(P.cum16) + ((size_t)p.shell * P.cum16_stride + (unsigned)mb0);
                 if (in_macro) {
-                    event = draw();
+                    if (!redo) event = draw();
                     x = (unsigned)(event * 65536.0);  // floor: event is in [0, 1)
-                    q_hi = (mb1 + 7) >> 3;
                 }
-                if (H.debug_flags & 16384) dbg_walk += (unsigned)__popcll(__ballot(in_macro && mb1 > 8 * WALK_WINDOW_QUADS));  // tests: jumps out of long blocks
+                const bool hot = in_macro && mb1 < 0, cold = in_macro && mb1 >= 0;
+                int q_lo = 0, q_hi = cold ? (mb1 + 7) >> 3 : 0;
+                const MC_G unsigned short *__restrict__ blk = glob(P.cum16) + ((size_t)p.shell * P.cum16_stride + (unsigned)(cold ? mb0 : 0));
+                if (H.debug_flags & 16384) dbg_walk += (unsigned)__popcll(__ballot(cold && mb1 > 8 * WALK_WINDOW_QUADS));  // tests: jumps out of long blocks
                 // blocks of more than 32 transitions: first quad whose last entry is not below x (entries are monotone)
-                while (__ballot(in_macro && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1)) {
-                    if (in_macro && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1) {
+                while (__ballot(cold && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1)) {
+                    if (cold && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1) {
                         const int qm = q_lo + ((q_hi - q_lo) >> 1);
                         const unsigned v = blk[8 * qm + 7];
                         if (v < x) q_lo = qm + 1; else q_hi = qm;
                     }
                 }
+                // ---- first round trip of the jump: the window of a cold block / the sector of a hot one (same registers)
                 int sel = -1;  // position of the selected transition in its block; -1: the block ran out
                 bool exact = false;
+                int nxt = 0;   // second round trip: 1 rec16[mb0 + sel], 2 blk_tab[nxt_arg], 3 nu_line[emit]
+                unsigned nxt_arg = 0;
                 if (in_macro) {
-                    const int n_quads = (mb1 + 7) >> 3;
-                    const int nq = min(WALK_WINDOW_QUADS, n_quads - q_lo);
+                    const int nq = hot ? 4 : min(WALK_WINDOW_QUADS, ((mb1 + 7) >> 3) - q_lo);
                     typedef unsigned u4v __attribute__((ext_vector_type(4)));
-                    const MC_G u4v *__restrict__ wp = reinterpret_cast<const MC_G u4v *>(blk + 8 * q_lo);
+                    const MC_G u4v *__restrict__ wp = hot ? reinterpret_cast<const MC_G u4v *>(glob(P.hot_sec) + ((size_t)p.shell * (size_t)P.hot_stride + (size_t)(unsigned)mb0 * 16))
+                                                          : reinterpret_cast<const MC_G u4v *>(blk + 8 * q_lo);
                     uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
                     if (nq > 0) { const u4v t = wp[0]; w0 = make_uint4(t.x, t.y, t.z, t.w); }
                     if (nq > 1) { const u4v t = wp[1]; w1 = make_uint4(t.x, t.y, t.z, t.w); }
                     if (nq > 2) { const u4v t = wp[2]; w2 = make_uint4(t.x, t.y, t.z, t.w); }
                     if (nq > 3) { const u4v t = wp[3]; w3 = make_uint4(t.x, t.y, t.z, t.w); }
-                    const unsigned xx = x | (x << 16);
-                    unsigned less = 0, gt = 0;
-                    if (nq > 0) walk_count_quad(w0, xx, less, gt);
-                    if (nq > 1) walk_count_quad(w1, xx, less, gt);
-                    if (nq > 2) walk_count_quad(w2, xx, less, gt);
-                    if (nq > 3) walk_count_quad(w3, xx, less, gt);
-                    const int n_less = (int)((less & 0xffffu) + (less >> 16)), n_gt = (int)((gt & 0xffffu) + (gt >> 16));
-                    int k = 8 * q_lo + n_less;  // every entry before it is surely <= the number drawn
-                    if (8 * nq - n_gt - n_less > 0) {
-                        exact = true;
-                        // entries equal to x (2^-16 of the draws per entry; the 0xffff padding when x = 65535): the reference's
-                        // own comparison on the fp64 running sums, in order
-                        const MC_G double *__restrict__ cum = glob(P.cum_t) + (size_t)p.shell * (size_t)P.n_trans;
-                        for (; k < mb1; ++k) {
-                            const unsigned v = blk[k];
-                            if (v > x) break;
-                            const int2 qi = gload(P.quad_info + ((unsigned)(mb0 + k) >> 3));
-                            if (cum[(unsigned)(qi.x + (k & 7))] > event) break;
+                    if (hot) {
+                        const unsigned lo2[3] = {w0.x, w0.y, w0.z}, hi2[3] = {w0.w, w1.x, w1.y}, k2[3] = {w3.x, w3.y, w3.z};
+                        const unsigned dw[HOT_ENTRIES] = {w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+                        bool hit = false;
+                        unsigned d = 0, k16 = 0;
+#pragma unroll
+                        for (int e = 0; e < HOT_ENTRIES; ++e) {
+                            const unsigned sh16 = 16u * (unsigned)(e & 1);
+                            const unsigned l = (lo2[e >> 1] >> sh16) & 0xffffu, h = (hi2[e >> 1] >> sh16) & 0xffffu;
+                            if (x >= l && x < h) { hit = true; d = dw[e]; k16 = (k2[e >> 1] >> sh16) & 0xffffu; }  // (the intervals are disjoint)
                         }
+                        if (hit) {
+                            macro += k16 + 1u;
+                            if (d & WALK_EMIT) { emit = (int)(d & 0x7fffffffu); in_macro = false; nxt = 3; }
+                            else if (d & WALK_HOT_DEST) mb0 = (int)(d & 0x3fffffffu);
+                            else { nxt = 2; nxt_arg = d; }
+                        } else { redo = true; nxt = 2; nxt_arg = (unsigned)mb0; }
+                    } else {
+                        const unsigned xx = x | (x << 16);
+                        unsigned less = 0, gt = 0;
+                        if (nq > 0) walk_count_quad(w0, xx, less, gt);
+                        if (nq > 1) walk_count_quad(w1, xx, less, gt);
+                        if (nq > 2) walk_count_quad(w2, xx, less, gt);
+                        if (nq > 3) walk_count_quad(w3, xx, less, gt);
+                        const int n_less = (int)((less & 0xffffu) + (less >> 16)), n_gt = (int)((gt & 0xffffu) + (gt >> 16));
+                        int k = 8 * q_lo + n_less;  // every entry before it is surely <= the number drawn
+                        if (8 * nq - n_gt - n_less > 0) {
+                            exact = true;
+                            // entries equal to x (2^-16 of the draws per entry; the 0xffff padding when x = 65535): the reference's
+                            // own comparison on the fp64 running sums, in order
+                            const MC_G double *__restrict__ cum = glob(P.cum_t) + (size_t)p.shell * (size_t)P.n_trans;
+                            for (; k < mb1; ++k) {
+                                const unsigned v = blk[k];
+                                if (v > x) break;
+                                const int2 qi = gload(P.quad_info + ((unsigned)(mb0 + k) >> 3));
+                                if (cum[(unsigned)(qi.x + (k & 7))] > event) break;
+                            }
+                        }
+                        if (k < mb1) sel = k;
+                        macro += (unsigned)(sel >= 0 ? sel + 1 : mb1);
+                        redo = false;
+                        if (sel < 0) { err = ERR_MACRO_ATOM; in_macro = false; }
+                        else nxt = 1;
                     }
-                    if (k < mb1) sel = k;
-                    macro += (unsigned)(sel >= 0 ? sel + 1 : mb1);
                 }
                 if (H.debug_flags & 32768) dbg_walk += (unsigned)__popcll(__ballot(exact));  // tests: jumps decided by the fp64 sums
-                if (in_macro) {
-                    if (sel < 0) { err = ERR_MACRO_ATOM; in_macro = false; }
-                    else {
-                        const WalkRec rec = gload(P.rec16 + (unsigned)(mb0 + sel));
-                        if (rec.b & WALK_EMIT) {
-                            emit = (int)rec.a;
-                            emit_nu_walk = rec.nu;  // (the emission line's frequency travels with the record: no read of nu_line afterwards)
-                            in_macro = false;
-                            if (rec.b & WALK_UNSUPPORTED) err = ERR_UNSUPPORTED;
-                        } else { mb0 = (int)rec.a; mb1 = (int)rec.b; }
-                    }
-                }
+                if (H.debug_flags & 65536) dbg_walk += (unsigned)__popcll(__ballot(hot && !redo));  // tests: jumps decided by a hot sector
+                if (H.debug_flags & 131072) dbg_walk += (unsigned)__popcll(__ballot(hot && redo));  // tests: numbers a hot sector did not decide
+                // ---- second round trip: what the selected transition leads to
+                if (nxt == 1) {
+                    const WalkRec rec = gload(P.rec16 + (unsigned)(mb0 + sel));
+                    if (rec.b & WALK_EMIT) {
+                        emit = (int)rec.a;
+                        emit_nu_walk = rec.nu;  // (the emission line's frequency travels with the record: no read of nu_line afterwards)
+                        in_macro = false;
+                        if (rec.b & WALK_UNSUPPORTED) err = ERR_UNSUPPORTED;
+                    } else { mb0 = (int)rec.a; mb1 = (rec.b & WALK_HOT) ? -1 : (int)rec.b; }
+                } else if (nxt == 2) {
+                    const int2 bt = gload(P.blk_tab + nxt_arg);
+                    mb0 = bt.x; mb1 = bt.y;
+                } else if (nxt == 3)
+                    emit_nu_walk = glob(P.nu_line)[(unsigned)emit];  // (the sector the coming sweep starts in)
             }
             if (in_macro) {  // carried over
                 state = WS_WALK;
                 sh.chi[lane] = inv_new;
-                reinterpret_cast<int2 *>(sh.rcp_chi)[lane] = make_int2(mb0, mb1);
+                reinterpret_cast<int2 *>(sh.rcp_chi)[lane] = make_int2(mb0, redo ? (mb1 | WALK_REDO) : mb1);
+                if (redo) sh.tau_event[lane] = event;
             }
         } else if (P.line_interaction_type == 2 && !(P.debug_flags & 128)) {  // (flag 128: the per-lane search below, for tests)
             // macroatom mode (long chains of jumps, and a wave waits for its longest chain: one coalesced round trip per jump): the wave's G-lane groups scan the blocks, G
@@ -1797,7 +1833,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             }
         }
         if (H.debug_flags & 16) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
-        if (H.debug_flags & (16384 | 32768)) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_walk);  // tests only
+        if (H.debug_flags & (16384 | 32768 | 65536 | 131072)) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_walk);  // tests only
         if (H.debug_flags & 2097152) gatomic_add_u64(&C->counters[7], dbg_drain_t0 ? wall_clock64() - dbg_drain_t0 : 0ull);
         if (H.debug_flags & 4194304) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_drain_passes);
         if (H.debug_flags & 8388608) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_drain_lanes);

@@ -100,6 +100,14 @@ struct TardisMcContext {
     int n_lines = 0, n_trans = 0, n_levels = 0;
     DevBuf nu_line, tau_t, n_e, prob_t, cum_t, trans_nu, line2level, block_edge, ttype, dest, tline, staging, line_block, trans_rec, bucket_first;
     DevBuf cum16, rec16, quad_info, line_block_c;  // compact walk tables (walk_tables.hpp)
+    DevBuf hot_sec, hot_mass, hot_flag, blk_tab;   // hot sectors of the macro-atom walk (walk_tables.hpp)
+    bool have_hot = false;
+    long long n_hot_blocks = 0;                    // blocks entered through a hot sector (diagnostic)
+    int walk_hot = -1;                             // -1: blocks whose six widest intervals cover enough (walk_hot_min_mass); 0: none; 1: every block
+    // per mille of a block's probability, mean over the shells; blocks of <= 32 / more rows.  Measured (profiles/r04_walk_hot_sectors.txt):
+    // heavy-tailed blocks -11 % whatever the thresholds (95 % of their jumps are decided by the sector); blocks of 12-24 rows with
+    // uniformly drawn probabilities (six intervals cover ~50-70 %) lose 2.5 % at 600 -- a missed probe costs a round of the walk
+    int walk_hot_min_mass = 800, walk_hot_min_mass_long = 400;
     DevBuf tau_pfx, tau_rowsum, pfx_flag;          // v-packet screening tables (tau_prefix.hpp), built at the first SCREENING call after set_opacity (+ their negative-depth flag)
     bool pfx_valid = false, pfx_negative = false;
     unsigned cum16_stride = 0;
@@ -613,6 +621,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     for (auto &b : ctx->li_i64) b.release();
     ctx->li_rec.release();
     ctx->cum16.release(); ctx->rec16.release(); ctx->quad_info.release(); ctx->line_block_c.release();
+    ctx->hot_sec.release(); ctx->hot_mass.release(); ctx->hot_flag.release(); ctx->blk_tab.release();
     ctx->tau_pfx.release(); ctx->tau_rowsum.release();
     ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
     ctx->vq_req.release(); ctx->vq_items.release(); ctx->vq_count.release(); ctx->vq_jsave.release();
@@ -643,6 +652,9 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "drain_split") ctx->drain_split = value ? 1 : 0;
     else if (n == "walk_sector_packing") ctx->walk_sector_packing = value ? 1 : 0;
+    else if (n == "walk_hot") ctx->walk_hot = value < 0 ? -1 : (value ? 1 : 0);  // (like walk_sector_packing: before set_opacity)
+    else if (n == "walk_hot_min_mass") ctx->walk_hot_min_mass = (int)std::max<long long>(0, std::min<long long>(value, 1001));
+    else if (n == "walk_hot_min_mass_long") ctx->walk_hot_min_mass_long = (int)std::max<long long>(0, std::min<long long>(value, 1001));
     else if (n == "vpacket_screening") ctx->vpacket_screening = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
     else if (n == "lane_sweep_min_active") ctx->ls_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
@@ -780,6 +792,8 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         }
     }
     ctx->have_walk_tables = false;
+    ctx->have_hot = false;
+    ctx->n_hot_blocks = 0;
     ctx->pfx_valid = false;  // (the prefix sums of the new tau table are built by the first propagate call that traces v-packets)
     if (macro && E > 1 && !ctx->prob_negative) {
         // compact tables of the per-lane macro-atom walk (walk_tables.hpp): blocks at 16-byte aligned compact offsets.  The walk is
@@ -802,6 +816,49 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         const long long n_quads = tc / 8;
         const unsigned long long stride = ((unsigned long long)tc + 31ull) / 32ull * 32ull + mc::WALK_SLACK;  // (rows start on sector boundaries)
         if (tc > 0 && stride * S < (1ull << 32) && tc < (1LL << 30)) {
+            // hot sectors (walk_tables.hpp): measured on the device (total width of a block's six widest intervals, per shell),
+            // chosen here (mean over the shells), then built once more with the destinations' flags in place
+            std::vector<unsigned char> hot(n_levels, 0);
+            if (ctx->walk_hot != 0 && n_levels < (size_t)mc::WALK_HOT) {
+                const long long nb = (long long)n_levels * (long long)S;
+                HIP_TRY(ctx, ctx->hot_sec.ensure((size_t)nb * 64));
+                HIP_TRY(ctx, ctx->hot_mass.ensure((size_t)nb * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->hot_flag.ensure(n_levels));
+                auto launch_hot = [&](const unsigned char *flags, unsigned *mass) {
+                    hipLaunchKernelGGL(mc::walk_hot_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream, ctx->cum_t.as<double>(),
+                                       ctx->block_edge.as<int>(), ctx->ttype.as<int>(), ctx->dest.as<int>(), ctx->tline.as<int>(), flags,
+                                       (int)n_levels, (long long)T, (int)S, ctx->hot_sec.as<unsigned>(), mass);
+                    return hipGetLastError();
+                };
+                HIP_TRY(ctx, launch_hot(nullptr, ctx->hot_mass.as<unsigned>()));
+                std::vector<unsigned> mass((size_t)nb);
+                HIP_TRY(ctx, hipMemcpyAsync(mass.data(), ctx->hot_mass.p, (size_t)nb * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                for (size_t b = 0; b < n_levels; ++b) {
+                    const long long rows = o->macro_block_edge_index[b + 1] - o->macro_block_edge_index[b];
+                    if (rows <= 0) continue;
+                    double m = 0.0;
+                    for (size_t sh = 0; sh < S; ++sh) m += (double)mass[sh * n_levels + b];
+                    m /= 65536.0 * (double)S;
+                    const double need = 1e-3 * (double)(rows > 8 * mc::WALK_WINDOW_QUADS ? ctx->walk_hot_min_mass_long : ctx->walk_hot_min_mass);
+                    if (ctx->walk_hot == 1 || m >= need) { hot[b] = 1; ctx->n_hot_blocks += 1; }
+                }
+                if (ctx->n_hot_blocks > 0) {
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->hot_flag.p, hot.data(), n_levels, hipMemcpyHostToDevice, ctx->stream));
+                    HIP_TRY(ctx, launch_hot(ctx->hot_flag.as<unsigned char>(), nullptr));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    ctx->have_hot = true;
+                }
+            }
+            {
+                std::vector<int> bt(2 * n_levels);
+                for (size_t b = 0; b < n_levels; ++b) {
+                    bt[2 * b] = (int)c0[b];
+                    bt[2 * b + 1] = (int)(o->macro_block_edge_index[b + 1] - o->macro_block_edge_index[b]);
+                }
+                if ((rc = upload(ctx, ctx->blk_tab, bt.data(), bt.size()))) return rc;
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            }
             std::vector<int> qi(2 * (size_t)n_quads, 0), lbc(2 * L, 0);  // (quads of the sector padding: {0, 0} -> eight 0xffff entries)
             std::vector<mc::WalkRec> r16((size_t)tc + 1, mc::WalkRec{0u, 0u, 0.0});
             for (size_t b = 0; b < n_levels; ++b) {
@@ -812,8 +869,11 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
                     const int64_t tt = o->transition_type[k];
                     if (tt >= 0) {
                         const int64_t lvl = o->destination_level_id[k];
-                        r16[c].a = (unsigned)c0[lvl];
-                        r16[c].b = (unsigned)(o->macro_block_edge_index[lvl + 1] - o->macro_block_edge_index[lvl]);
+                        if (hot[lvl]) { r16[c].a = (unsigned)lvl; r16[c].b = mc::WALK_HOT; }
+                        else {
+                            r16[c].a = (unsigned)c0[lvl];
+                            r16[c].b = (unsigned)(o->macro_block_edge_index[lvl + 1] - o->macro_block_edge_index[lvl]);
+                        }
                     } else if (tt == -1) {
                         r16[c].a = (unsigned)o->transition_line_id[k];
                         r16[c].b = mc::WALK_EMIT;
@@ -824,8 +884,11 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
             }
             for (size_t i = 0; i < L; ++i) {
                 const int64_t lvl = o->line2macro_level_upper[i];
-                lbc[2 * i] = (int)c0[lvl];
-                lbc[2 * i + 1] = (int)(o->macro_block_edge_index[lvl + 1] - o->macro_block_edge_index[lvl]);
+                if (hot[lvl]) { lbc[2 * i] = (int)lvl; lbc[2 * i + 1] = -1; }
+                else {
+                    lbc[2 * i] = (int)c0[lvl];
+                    lbc[2 * i + 1] = (int)(o->macro_block_edge_index[lvl + 1] - o->macro_block_edge_index[lvl]);
+                }
             }
             if ((rc = upload(ctx, ctx->quad_info, qi.data(), qi.size()))) return rc;
             if ((rc = upload(ctx, ctx->rec16, r16.data(), r16.size()))) return rc;
@@ -1297,6 +1360,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             P.cum16 = ctx->cum16.as<unsigned short>(); P.rec16 = ctx->rec16.as<mc::WalkRec>(); P.quad_info = ctx->quad_info.as<int2>();
             P.cum16_stride = ctx->cum16_stride;
             P.line_block = ctx->line_block_c.as<int2>();
+            P.hot_sec = ctx->have_hot ? ctx->hot_sec.as<unsigned>() : nullptr;
+            P.blk_tab = ctx->blk_tab.as<int2>();
+            P.hot_stride = (unsigned)(16u * (unsigned)ctx->n_levels);
         }
         const bool full = c.enable_full_relativity != 0, trk = ctx->track;
         while ((int)ctx->ev_chunk.size() < 8) {

@@ -19,6 +19,24 @@
 //   quad_info[q]  = {original transition index of compact entry 8 q, entries from there to the end of its block}: maps a
 //                   compact index back to cum_t for the exact comparison.
 //   line_block_c[line] = {c0, rows} of the block the line activates.
+//
+// Hot sectors (round 4).  A jump costs two dependent requests (running sums, then the record of the selected transition), a
+// jump out of a long block a binary search on top -- and real macro-atom blocks are long and skewed: a few transitions carry
+// nearly all of a block's probability (A-values times escape probabilities span decades).  For such blocks
+//   hot_sec[s][b] = ONE 64-byte sector per (shell, block): the up to six widest intervals [cum(k-1), cum(k)) of the block as
+//                   {lo, hi} in 16-bit units, what transition k leads to, and k itself (the reference counts the
+//                   transitions it examined):   dwords 0-2 lo x 6 | 3-5 hi x 6 | 6-11 dest x 6 | 12-14 k x 6 | 15 total width
+//                   With x = floor(xi * 65536):   lo <= x < hi   =>   cum(k-1) <= xi < cum(k)   (lo = floor(cum(k-1) * 65536) + 1, or 0
+//                   for the first transition; hi = floor(cum(k) * 65536), both saturating at 65535: floor(y) + 1 > y and
+//                   floor(y) <= y), i.e. transition k is the reference's choice; the order of the entries does not matter.
+//                   A number that falls into none of the six (a narrow interval, a tie at an interval's end) is looked up in
+//                   the block's own tables as before -- the SAME number, in the next round of the walk.
+//                   dest = line id | WALK_EMIT, or block id [| WALK_HOT_DEST when that block is entered through its hot sector].
+//   blk_tab[b]    = {c0, rows}: the block's own tables, for the numbers its hot sector does not decide (and for the cold
+//                   destinations of hot entries); 8 bytes per block, cache resident.
+// A block gets a hot sector when the six intervals cover enough of it on average over the shells (walk_hot_min_mass; blocks of
+// more than one window need less: their cold jump starts with a binary search).  line_block_c / rec16 then name the block by
+// {block id, -1} / {block id, WALK_HOT} instead of {c0, rows}.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,6 +44,10 @@
 namespace mc {
 
 constexpr unsigned WALK_EMIT = 0x80000000u, WALK_UNSUPPORTED = 0x40000000u;
+constexpr unsigned WALK_HOT = 0x20000000u;        // rec16[].b of an internal transition: the destination block is entered through its hot sector (a = block id)
+constexpr unsigned WALK_HOT_DEST = 0x40000000u;   // dest word of a hot-sector entry: likewise
+constexpr int WALK_REDO = 0x40000000;             // parked walk state (rows | WALK_REDO): the number drawn is looked up again, in the block's own tables
+constexpr int HOT_ENTRIES = 6;
 struct __attribute__((aligned(16))) WalkRec {
     unsigned a, b;  // internal transition: compact start and rows of the destination block; emission: line id, WALK_EMIT [| WALK_UNSUPPORTED]
     double nu;      // emission: frequency of the line (line_emission, interaction_events.py:227-258, needs it next)
@@ -57,6 +79,59 @@ __global__ void __launch_bounds__(256) walk_cum16_kernel(const double *__restric
     uint4 out;
     out.x = v[0] | (v[1] << 16); out.y = v[2] | (v[3] << 16); out.z = v[4] | (v[5] << 16); out.w = v[6] | (v[7] << 16);
     reinterpret_cast<uint4 *>(cum16 + (size_t)s * stride)[q] = out;
+}
+
+// one thread per (block, shell): the six widest 16-bit intervals of the block's running sums -> its hot sector; `mass` = their
+// total width (of 65536).  Only emissions (type -1) and internal transitions (type >= 0) are eligible; `hot_flag` (null in the
+// first of the two passes, which only measures) marks the destination blocks that are themselves entered through hot sectors.
+__global__ void __launch_bounds__(256) walk_hot_kernel(const double *__restrict__ cum_t, const int *__restrict__ block_edge,
+                                                        const int *__restrict__ ttype, const int *__restrict__ dest, const int *__restrict__ tline,
+                                                        const unsigned char *__restrict__ hot_flag, int n_blocks, long long n_trans, int n_shells,
+                                                        unsigned *__restrict__ hot_sec, unsigned *__restrict__ mass)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n_blocks * n_shells) return;
+    const int b = (int)(i % n_blocks), s = (int)(i / n_blocks);
+    const double *c = cum_t + (long long)s * n_trans;
+    const int b0 = block_edge[b], b1 = block_edge[b + 1];
+    unsigned lo[HOT_ENTRIES], hi[HOT_ENTRIES], dw[HOT_ENTRIES], kk[HOT_ENTRIES], wd[HOT_ENTRIES];
+#pragma unroll
+    for (int e = 0; e < HOT_ENTRIES; ++e) { lo[e] = 1; hi[e] = 0; dw[e] = 0; kk[e] = 0; wd[e] = 0; }
+    unsigned prev16 = 0;  // floor(cum(k-1) * 65536), saturated
+    for (int k = b0; k < b1; ++k) {
+        const double t = c[k] * 65536.0;
+        const unsigned cur16 = t >= 65535.0 ? 65535u : (t > 0.0 ? (unsigned)t : 0u);
+        const unsigned l = k == b0 ? 0u : prev16 + 1u, h = cur16;
+        prev16 = cur16;
+        const int tt = ttype[k];
+        if (h <= l || tt < -1 || k - b0 >= 65535) continue;
+        unsigned d;
+        if (tt == -1) d = (unsigned)tline[k] | WALK_EMIT;
+        else {
+            const int lvl = dest[k];
+            d = (unsigned)lvl | ((hot_flag && hot_flag[lvl]) ? WALK_HOT_DEST : 0u);
+            if ((unsigned)lvl >= WALK_HOT_DEST) continue;
+        }
+        unsigned w = h - l, nl = l, nh = h, nd = d, nk = (unsigned)(k - b0);
+#pragma unroll
+        for (int e = 0; e < HOT_ENTRIES; ++e)  // insertion into the (descending) list of the widest six
+            if (w > wd[e]) {
+                unsigned t0 = wd[e]; wd[e] = w; w = t0;
+                t0 = lo[e]; lo[e] = nl; nl = t0;
+                t0 = hi[e]; hi[e] = nh; nh = t0;
+                t0 = dw[e]; dw[e] = nd; nd = t0;
+                t0 = kk[e]; kk[e] = nk; nk = t0;
+            }
+    }
+    unsigned total = 0;
+#pragma unroll
+    for (int e = 0; e < HOT_ENTRIES; ++e) total += wd[e];
+    uint4 *out = reinterpret_cast<uint4 *>(hot_sec + ((size_t)s * (size_t)n_blocks + (size_t)b) * 16);
+    out[0] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), hi[0] | (hi[1] << 16));
+    out[1] = make_uint4(hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), dw[0], dw[1]);
+    out[2] = make_uint4(dw[2], dw[3], dw[4], dw[5]);
+    out[3] = make_uint4(kk[0] | (kk[1] << 16), kk[2] | (kk[3] << 16), kk[4] | (kk[5] << 16), total);
+    if (mass) mass[(size_t)s * (size_t)n_blocks + (size_t)b] = total;
 }
 
 // packed u16 counting: for the two entries of a dword, +1 in the respective half of `less` where entry < x and of `gt`

@@ -26,13 +26,18 @@ if os.environ.get("EXP_LOG_TAU"):  # thinner / thicker lines than the default sy
     shape["log_tau_mean"] = float(os.environ["EXP_LOG_TAU"])
 if os.environ.get("EXP_NE0"):
     shape["electron_density_0"] = float(os.environ["EXP_NE0"])
+if os.environ.get("EXP_LEVELS"):  # "heavy": heavy-tailed macro-atom blocks (synthetic.make_opacity_state)
+    shape["level_sizes"] = os.environ["EXP_LEVELS"]
 prob = synthetic.make_problem(seed=1, n_packets=1, **shape)
 eng = Engine(0)
 eng.set_geometry(prob.geometry, prob.time_explosion)
 eng.set_opacity(prob.opacity_state)
 eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
 defaults = {"variant": -1, "debug_flags": 0, "group_size": 0, "lane_sweep_min_active": 8, "lane_sweep_max_steps": 1 << 30, "waves_per_simd": 4,
-            "track_last_interaction": 1}
+            "track_last_interaction": 1, "walk_hot": -1, "walk_hot_min_mass": int(os.environ.get("EXP_HOT_SHORT", 800)),
+            "walk_hot_min_mass_long": int(os.environ.get("EXP_HOT_LONG", 400)), "walk_sector_packing": 1}
+TABLE_OPTIONS = ("walk_hot", "walk_hot_min_mass", "walk_hot_min_mass_long", "walk_sector_packing")  # take effect in set_opacity
+table_state = (-1, 800, 400, 1)  # the engine's defaults, in force for the set_opacity above
 ref = None
 for e in exps:
     opts = dict(defaults)
@@ -42,6 +47,10 @@ for e in exps:
             opts[k] = int(v)
     for k, v in opts.items():
         eng.set_option(k, v)
+    ts = tuple(opts[k] for k in TABLE_OPTIONS)
+    if ts != table_state and table_state is not None:
+        eng.set_opacity(prob.opacity_state)
+    table_state = ts
     eng.create_blackbody_packets(P, float(prob.geometry.r_inner[0]), 1.0e4)
     best = 1e30
     for _ in range(2):
