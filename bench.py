@@ -16,7 +16,10 @@ configs[3]: 1e8 packets on 8 GPUs = 1.25e7 each).
 
 Workload (default, N = 1): BASELINE.json configs[2], the configuration the metric is quoted on -- full-Kurucz-sized
 line list (5e5 lines), macroatom line interaction, 20 shells, **1e8 packets per step**, no v-packets, last-interaction
-tracking on; synthetic opacities (the reference's atomic data is not available offline).  The packets are
+tracking on; synthetic opacities (the reference's atomic data is not available offline).  Since round 4 the
+macro-atom blocks of the headline are the HEAVY-TAILED ones (`--level-sizes heavy`: a block is all transitions out of one
+level, a few to 18 000 rows, probabilities over many decades -- what real Kurucz data looks like and what TARDIS would feed the
+kernel); the 4-8-line levels of rounds 1-3 (`--level-sizes uniform`) are the `extra.uniform_levels` leg.  The packets are
 drawn by the device packet source (BlackBodySimpleSource.create_packets with NumPy's PCG64 streams
 reproduced by jump-ahead), so the host never builds the 4 GB of inputs; rank r draws packets [r P, (r+1) P) of the
 N P-packet stream.  `--config 2` selects configs[1] (tardis_example shape, 3e4 lines, downbranch, 1e7 packets).
@@ -29,7 +32,9 @@ workload, with the GPU-vs-CPU parity of that sample) and `boundary` (one full dr
 a bounded packet count: the PCIe-inclusive rate; never `value`).  The default N = 1 line also carries `extra`: the same
 timed-step structure on (a) the headline's tables with heavy-tailed macro-atom blocks and (b) BASELINE configs[4]'s table
 shape (100 shells, macroatom, ten v-packets per interaction) at 1e7 packets, each with its own `roofline` and the parity of a
-small sample against the CPU oracle (`--no-extra` skips them).
+small sample against the CPU oracle (`--no-extra` skips them), and `strong_scaling_model`: one call of the headline workload at
+1/8 of its packets -- the share of one GPU under BASELINE configs[3] (1e8 packets on 8 GPUs) -- whose rate against the headline's
+is what strong scaling can reach before a byte crosses xGMI (a call ends with the drain of its longest-lived packets).
 """
 from __future__ import annotations
 
@@ -74,16 +79,16 @@ def algorithmic_bytes(c: dict, part: str = "step", screened: bool = False) -> fl
 def walk_bytes(c: dict) -> float:
     """Macro-atom term of the byte model.  SURVEY §8(d) prices the reference's serial walk: 8 B per transition examined (M).
     With heavy-tailed blocks M is tens of thousands per packet and a serial walk is no lower bound any more: a jump is a
-    search in the block's running sums, which needs one 64-byte window of them and the 16-byte record of the selected
-    transition.  So the term is min(8 M, 80 J) with J = rng_draws - 2 events, a LOWER bound of the number of jumps (every
-    event draws tau_event, at most every event ends in an interaction that draws a direction, every jump draws once; only
-    without v-packets, whose draws are not jumps).  On the 4-8-line levels of rounds 1-2 both sides agree to 0.3 % (9 rows
-    examined per jump)."""
+    search in the block's running sums, which needs at least one 64-byte sector per jump (round 3: a 64-byte window of the
+    sums and the 16-byte record of the selected transition, 80 B; round 4: the block's hot sector, 64 B).  So the term is
+    min(8 M, 64 J) with J = rng_draws - 2 events, a LOWER bound of the number of jumps (every event draws tau_event, at most
+    every event ends in an interaction that draws a direction, every jump draws once; only without v-packets, whose draws
+    are not jumps).  On the 4-8-line levels of rounds 1-2, 8 M = 9 rows per jump = 72 B per jump."""
     serial = 8.0 * c["macro_transitions"]
     if c["vpackets"] > 0 or c["macro_transitions"] == 0:
         return serial
     jumps_lb = max(c["rng_draws"] - 2 * c["events"], 0)
-    return min(serial, 80.0 * jumps_lb)
+    return min(serial, 64.0 * jumps_lb)
 
 
 EXTRA_LEGS_DEADLINE_S = 270.0  # the extra legs (~25 s + ~30 s) only start while the whole run is younger than this
@@ -103,9 +108,10 @@ def main():
     ap.add_argument("--shells", type=int, default=None)
     ap.add_argument("--mode", type=str, default=None)
     ap.add_argument("--vpackets", type=int, default=None)
-    ap.add_argument("--level-sizes", type=str, default="uniform", choices=["uniform", "heavy"],
-                    help="macro-atom block sizes of the synthetic opacity state: 'uniform' = 4-8 lines per level (rounds 1-2), "
-                         "'heavy' = heavy-tailed (Pareto, up to 6000 lines = 18000 rows per block, probabilities over many decades)")
+    ap.add_argument("--level-sizes", type=str, default=None, choices=["uniform", "heavy"],
+                    help="macro-atom block sizes of the synthetic opacity state: 'heavy' = heavy-tailed (Pareto, up to 6000 lines = "
+                         "18000 rows per block, probabilities over many decades; the default of the macroatom configs since round 4), "
+                         "'uniform' = 4-8 lines per level (rounds 1-3; the default of the tardis_example-shaped config 2)")
     ap.add_argument("--scaling", type=str, default="weak", choices=["weak", "strong"],
                     help="N > 1: 'weak' = every rank owns the config's packets per step (N x packets per iteration); 'strong' = "
                          "the config's packets are shared by the N ranks (BASELINE configs[3]: 1e8 packets on 8 GPUs)")
@@ -146,6 +152,9 @@ def main():
     elif args.config in (4, 5) and args.packets is None:
         kw["n_packets"] //= 8  # those configs quote the 8-GPU total
     P = int(kw.pop("n_packets"))
+    level_default = args.level_sizes is None
+    if level_default:
+        args.level_sizes = "heavy" if kw["line_interaction_type"] == "macroatom" else "uniform"
     # opacities, geometry, configuration on the host (same on every rank); the packets never exist on the host
     prob = synthetic.make_problem(seed=1, n_packets=1, level_sizes=args.level_sizes, **kw)
 
@@ -236,8 +245,10 @@ def main():
             n_b = args.boundary_packets if args.boundary_packets is not None else min(P, 10_000_000)
             if n_b > 0:
                 out["boundary"] = guarded(boundary_call, prob, eng, n_b, not args.no_tracking)
+    if pg.rank == 0 and n_gpus == 1 and args.config == 3 and args.scaling == "weak" and P >= 8_000_000:
+        out["strong_scaling_model"] = guarded(strong_scaling_model, eng, P, radius, value)
     eng.close()  # (frees the line-visit log before the extra legs allocate theirs)
-    default_line = (n_gpus == 1 and args.config == 3 and args.level_sizes == "uniform" and not args.option and not args.no_tracking
+    default_line = (n_gpus == 1 and args.config == 3 and level_default and not args.option and not args.no_tracking
                     and all(v is None for v in (args.packets, args.lines, args.shells, args.mode, args.vpackets, args.variant)))
     if pg.rank == 0 and default_line and not args.no_extra:
         dev = pg.local_rank if args.all_on_device is None else args.all_on_device
@@ -250,12 +261,30 @@ def main():
             return guarded(extra_leg, *a)
 
         out["extra"] = {
-            "heavy_tail": timely(dev, "configs[2] tables, heavy-tailed blocks", synthetic.BASELINE_CONFIGS[3], P, 2, 1, "heavy", 20_000, True),
-            "config5_shape": timely(dev, "configs[4] table shape", synthetic.BASELINE_CONFIGS[5], 10_000_000, 2, 1, "uniform", 3_000, True),
+            "uniform_levels": timely(dev, "configs[2] tables, 4-8-line levels (the headline of rounds 1-3)", synthetic.BASELINE_CONFIGS[3], P, 2, 1, "uniform", 20_000, True),
+            "config5_shape": timely(dev, "configs[4] table shape", synthetic.BASELINE_CONFIGS[5], 10_000_000, 2, 1, "heavy", 3_000, True),
         }
     if pg.rank == 0:
         print(json.dumps(out), flush=True)
     pg.destroy()
+
+
+def strong_scaling_model(eng, P: int, radius: float, headline_value: float, share: int = 8) -> dict:
+    """BASELINE configs[3] shares the headline's packets among 8 GPUs: every rank's iteration is ONE call of P / 8 packets, and a
+    call ends with the drain of its longest-lived packets (~0.2 s whatever the packet count).  Timed here on one
+    GPU: that call, after a warm-up call of the same size; `efficiency_bound` = its rate against the headline's = the strong
+    scaling efficiency 8 GPUs can reach before the all-reduce (160 MB over xGMI: ~2 ms) is added."""
+    n = P // share
+    eng.create_blackbody_packets(P, radius, T_INNER, first=0, count=n)
+    ms = []
+    for _ in range(3):
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        ms.append(eng.last_propagate_ms())
+    best = min(ms[1:])
+    return {"packets_per_call": n, "share_of": share, "device_ms": best, "all_ms": ms, "packets_per_s": n / (best * 1e-3),
+            "efficiency_bound": (n / (best * 1e-3)) / headline_value,
+            "note": "one propagate call of the headline workload at 1/8 of its packets (one GPU's share under BASELINE configs[3]) "
+                    "against the headline rate: the drain of a call bounds strong scaling before any byte crosses xGMI"}
 
 
 def guarded(leg, *a, **kw):
@@ -345,9 +374,9 @@ def measured_traffic(args, P: int, launches: int):
     """HBM bytes per launch of the propagation kernel from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes collected on this
     workload (tools/gpu_profile.sh -> profiles/pmc_traffic_config<N>.json, corrected as MI355X_MICROARCH.md prescribes);
     None when the file was collected on another workload."""
-    custom = (any(v is not None for v in (args.lines, args.shells, args.mode, args.vpackets, args.variant)) or args.no_tracking or args.option
-              or args.level_sizes != "uniform")
-    path = os.path.join(ROOT, "profiles", f"pmc_traffic_config{args.config}.json")
+    custom = any(v is not None for v in (args.lines, args.shells, args.mode, args.vpackets, args.variant)) or args.no_tracking or args.option
+    suffix = "_uniform_levels" if (args.level_sizes == "uniform" and args.config != 2) else ""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_config{args.config}{suffix}.json")
     if custom or not os.path.exists(path):
         return None
     try:

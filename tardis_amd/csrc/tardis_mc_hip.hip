@@ -283,6 +283,7 @@ __global__ void debug_eval_kernel(int op, const double *x, const double *y, doub
 //        6..9 every lane reads its own random, naturally aligned block of 16 / 32 / 64 / 128 bytes (dwordx4 loads);
 //        10 dependent chain: the address of a lane's next random 8-byte load comes out of the loaded value (latency);
 //        11 / 12 lane-private vs quad-shared 64-byte blocks (see below)
+//        13 / 14 packet hand-over through binned queues, 128- / 64-byte records (see below)
 __global__ void microbench_kernel(int which, double *table, long long n, int iters, double *sink)
 {
     const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -330,6 +331,32 @@ __global__ void microbench_kernel(int which, double *table, long long n, int ite
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc += v[q].x + v[q].y;
+        }
+    } else if (which == 13 || which == 14) {
+        // packet hand-over through binned queues (what re-binning the lanes of a wave by (shell, line tile) would cost per event,
+        // profiles/r04_locality.txt): a lane appends its packet -- a 128-byte (13) or 64-byte (14) record -- to the queue of a
+        // random one of 4900 bins (one returning atomic on the bin's cursor, 16-byte stores), and takes over a packet from a
+        // random slot of another bin (16-byte loads).  table = [4900 cursors | 4900 queues of `cap` records].
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const int rec_v2 = which == 13 ? 8 : 4;  // 16-byte pieces per record
+        const unsigned long long n_bins = 4900ull;
+        const unsigned long long cap = ((unsigned long long)n - 8192ull) / (n_bins * 2ull * (unsigned long long)rec_v2);
+        unsigned long long *cursor = reinterpret_cast<unsigned long long *>(table);
+        v2d *queues = reinterpret_cast<v2d *>(table + 8192);
+        for (int it = 0; it < iters; ++it) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            const unsigned long long b_out = (st >> 20) % n_bins, b_in = (st >> 40) % n_bins;
+            const unsigned long long slot = __hip_atomic_fetch_add(&cursor[b_out], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) % cap;
+            v2d *dst = queues + (b_out * cap + slot) * rec_v2;
+            const v2d rec = {acc, (double)it};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q < rec_v2) dst[q] = rec;
+            const v2d *src = queues + (b_in * cap + (st >> 7) % cap) * rec_v2;
+            v2d v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q < rec_v2) v[q] = src[q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q < rec_v2) acc += v[q].x + v[q].y;
         }
     } else if (which == 10) {
         unsigned long long r = st >> 20;

@@ -99,7 +99,7 @@ def test_hip_matches_oracle_and_reference_on_golden_cases(engine, oracle, name):
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("name", [n for n in _golden.CASES if "_nv2" in n or "_nv3" in n])
+@pytest.mark.parametrize("name", [n for n in _golden.CASES if "_nv2" in n or "_nv3" in n or "_nv10" in n])
 def test_every_kernel_variant_on_vpacket_golden_cases(engine, oracle, name, variant):
     """Whatever the automatic choice for a v-packet problem is, the group kernel, the wave-owner kernel's pooled volleys, its
     volley queue (variant 4: v-packets traced by a kernel of their own between its launches) and the lane kernel must all
@@ -411,12 +411,15 @@ def test_epochs_match_a_single_launch(oracle, variant):
 
 
 @pytest.mark.gpu
-def test_config5_shape_small(oracle):
+@pytest.mark.parametrize("level_sizes", ["uniform", "heavy"])
+def test_config5_shape_small(oracle, level_sizes):
     """BASELINE configs[4] shape (100 shells, 5e5 lines, macroatom, 10 v-packets) at a packet count the oracle finishes in
-    seconds: the largest table sizes of the baseline (24 500 estimator tiles, 144-KiB binning histograms)."""
+    seconds: the largest table sizes of the baseline (24 500 estimator tiles, 144-KiB binning histograms) -- on 4-8-line levels
+    and on heavy-tailed macro-atom blocks (what real atomic data looks like; the fixture-sized reference run of this combination
+    is the golden macroatom_heavy_100shells_nv10)."""
     from tardis_amd.engine import Engine
     prob = synthetic.make_problem(seed=23, n_packets=3_000, n_shells=100, n_lines=500_000, line_interaction_type="macroatom",
-                                  n_vpackets=10)
+                                  n_vpackets=10, level_sizes=level_sizes)
     ref = run_oracle(oracle, prob, n_threads=oracle.max_threads())
     eng = Engine(0)
     eng.set_geometry(prob.geometry, prob.time_explosion)

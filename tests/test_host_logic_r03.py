@@ -56,15 +56,16 @@ def _bench_module():
 
 def test_byte_model_of_the_bench():
     bench = _bench_module()
-    # rounds 1-2 workload (9 rows examined per jump): the SURVEY term 8 B x M stands
+    # the macro-atom term: min(8 B x rows the reference's serial walk examines, 64 B x jumps) -- a jump needs at least one
+    # 64-byte sector (round 4: the block's hot sector); J = rng_draws - 2 events is a lower bound of the jumps
     c = dict(line_visits=3278, events=91, macro_transitions=2385, vpacket_line_visits=0, vpackets=0, rng_draws=420, packets=1)
-    assert bench.walk_bytes(c) == min(8.0 * 2385, 80.0 * (420 - 2 * 91))
-    assert abs(bench.walk_bytes(c) - 8.0 * 2385) / (8.0 * 2385) < 0.01
+    assert bench.walk_bytes(c) == min(8.0 * 2385, 64.0 * (420 - 2 * 91)) == 64.0 * 238
+    assert bench.walk_bytes(dict(c, macro_transitions=1500)) == 8.0 * 1500  # (short blocks: the serial walk is the cheaper bound)
     assert bench.algorithmic_bytes(c, "step") == 48 * 3278 + 56 * 91 + bench.walk_bytes(c) + 56
     assert bench.algorithmic_bytes(c, "propagate") + bench.algorithmic_bytes(c, "estimators") == bench.algorithmic_bytes(c, "step")
-    # heavy-tailed blocks: the serial count is no lower bound of a search; one window + one record per jump is
+    # heavy-tailed blocks: the serial count is no lower bound of a search
     h = dict(c, macro_transitions=88_000)
-    assert bench.walk_bytes(h) == 80.0 * (420 - 182)
+    assert bench.walk_bytes(h) == 64.0 * (420 - 182)
     # v-packets: draws are not jumps (no cap), and with the screening the line visits of the v-packets are not bytes anyone moves
     v = dict(c, vpackets=812, vpacket_line_visits=225_000, rng_draws=2066)
     assert bench.walk_bytes(v) == 8.0 * 2385

@@ -1,6 +1,6 @@
 """The N > 1 path of bench.py on real hardware, as far as one GPU allows: two ranks (one process each, launched the way the
 driver launches them) share GPU 0.  RCCL refuses two ranks on one device, so the job takes bench.py's documented fall-back --
-the estimator arrays are summed through the control plane (gloo) -- which exercises everything else of the N > 1 path: the
+the estimator arrays are summed through the control plane (the package's TCP hub, tardis_amd/distributed.py) -- which exercises everything else of the N > 1 path: the
 rendezvous, rank r drawing packets [r P, (r+1) P) of the 2 P-packet stream on the device, barriers, max-over-ranks timing.
 The summed estimators must equal those of ONE rank propagating all 2 P packets (results are partition-invariant up
 to the summation order)."""
@@ -58,3 +58,24 @@ def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path):
     c = np.load(strong)
     for k in ("j_estimator", "nu_bar_estimator", "j_blue_shell_sums"):
         assert_allclose(c[k], b[k], rtol=1e-10, err_msg=k)
+
+
+def test_eight_ranks_launch_path_on_one_gpu(tmp_path):
+    """The N = 8 launch of the driver's scaling bench, run once for real: eight processes started by torch.distributed.run, the TCP
+    control plane with eight ranks, rank r drawing packets [r P, (r+1) P) of the 8 P-packet stream, the agreement that RCCL is not
+    available (eight ranks on one device), the host-side estimator sum, max-over-ranks timing, ONE JSON line from rank 0 -- and
+    the summed estimators of the eight shards equal one rank's run over all 8 P packets."""
+    P = 20_000
+    common = ["--config", "2", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--boundary-packets", "0"]
+    eight = tmp_path / "eight.npz"
+    one = tmp_path / "one.npz"
+    line8 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port()), "bench.py", "--gpus", "8", "--packets", str(P), "--all-on-device", "0",
+                  "--dump-estimators", str(eight)] + common, timeout=1500)
+    line1 = _run([sys.executable, "bench.py", "--gpus", "1", "--packets", str(8 * P), "--dump-estimators", str(one)] + common)
+    assert line8["n_gpus"] == 8 and line8["config"]["packets_per_gpu"] == P and line8["value"] > 0
+    assert "x8" in line8["config"]["parallelism"]
+    a, b = np.load(eight), np.load(one)
+    for k in ("j_estimator", "nu_bar_estimator", "j_blue_shell_sums", "edotlu_shell_sums", "j_blue_line_sums"):
+        assert_allclose(a[k], b[k], rtol=1e-10, err_msg=k)
+    assert line1["n_gpus"] == 1

@@ -67,6 +67,11 @@ CASES = {
     "macroatom_heavy_fullrel_nv2": (dict(seed=33, n_packets=400, n_shells=8, n_lines=4000, line_interaction_type="macroatom",
                                          n_vpackets=2, level_sizes="heavy", log_tau_mean=-2.0, enable_full_relativity=True),
                                     dict(ENABLE_VPACKET_TRACKING=True)),
+    # the BASELINE configs[4] combination at fixture size: 100 shells, macroatom on heavy-tailed blocks, ten v-packets per volley
+    # (each crossing up to 100 shells), consolidated v-packet log
+    "macroatom_heavy_100shells_nv10": (dict(seed=34, n_packets=400, n_shells=100, n_lines=3000, line_interaction_type="macroatom",
+                                            n_vpackets=10, level_sizes="heavy", log_tau_mean=-2.5, shell_independent_probabilities=True),
+                                       dict(ENABLE_VPACKET_TRACKING=True)),
     # quirk (iii) of SURVEY 8a: disable_line_scattering with non-zero tau_sobolev (real runs zero tau first, opacity_solver.py:46-56)
     "scatter_disabled_lines_tau": (dict(seed=21, n_packets=300, n_shells=6, n_lines=400, line_interaction_type="scatter",
                                         disable_line_scattering=True), {}),
