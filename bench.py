@@ -116,7 +116,7 @@ def main():
                     help="N > 1: 'weak' = every rank owns the config's packets per step (N x packets per iteration); 'strong' = "
                          "the config's packets are shared by the N ranks (BASELINE configs[3]: 1e8 packets on 8 GPUs)")
     ap.add_argument("--no-extra", action="store_true",
-                    help="skip the extra legs of the default N = 1 line (heavy-tailed macro-atom blocks; the configs[4] table shape)")
+                    help="skip the extra legs of the default N = 1 line (uniform levels; the configs[4] table shape) and the strong_scaling_model call")
     ap.add_argument("--no-tracking", action="store_true", help="skip the last-interaction tracker outputs")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="packets in the CPU-baseline sample (0: skip; default sized for ~15 s of CPU work)")
@@ -245,7 +245,7 @@ def main():
             n_b = args.boundary_packets if args.boundary_packets is not None else min(P, 10_000_000)
             if n_b > 0:
                 out["boundary"] = guarded(boundary_call, prob, eng, n_b, not args.no_tracking)
-    if pg.rank == 0 and n_gpus == 1 and args.config == 3 and args.scaling == "weak" and P >= 8_000_000:
+    if pg.rank == 0 and n_gpus == 1 and args.config == 3 and args.scaling == "weak" and P >= 8_000_000 and not args.no_extra:
         out["strong_scaling_model"] = guarded(strong_scaling_model, eng, P, radius, value)
     eng.close()  # (frees the line-visit log before the extra legs allocate theirs)
     default_line = (n_gpus == 1 and args.config == 3 and level_default and not args.option and not args.no_tracking

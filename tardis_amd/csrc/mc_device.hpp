@@ -35,11 +35,17 @@ struct __attribute__((aligned(8))) LineVisitRecord {
 static_assert(sizeof(LineVisitRecord) == 24, "record layout");
 
 struct EstimatorLog {
-    LineVisitRecord *records;          // [n_regions][region_capacity]: every wave appends to its own region (no atomics)
+    // The log is a pool of equal chunks (`region_capacity` records each); a wave appends to the chunk it holds (no atomics, no empty
+    // slots) and takes the next free one from the pool -- one atomic per chunk -- when that is full.  An epoch ends when the pool is
+    // empty: every wave then suspends within one chunk's worth of passes of the others.  (Rounds 1-3 gave every wave ONE region
+    // of capacity / waves records: the waves filled theirs at different times, and from the first suspension to the last -- 10-20 %
+    // of an epoch -- a growing part of the chip sat idle: 0.27 s of a 3.6-s step, profiles/r04_estimator_cost.txt.)
+    LineVisitRecord *records;          // [n_regions][region_capacity]
     unsigned *keys;                    // bin of each record, same layout
-    unsigned *region_count;            // [n_regions] records written by each wave (stored when the wave exits)
-    unsigned region_capacity;          // 0: no log, the kernels add their terms directly
-    int n_regions;
+    unsigned *region_count;            // [n_regions] records written to each chunk (stored when its wave leaves it)
+    unsigned *pool_next;               // next free chunk of the pool
+    unsigned region_capacity;          // records per chunk; 0: no log, the kernels add their terms directly
+    int n_regions;                     // chunks of the pool
     int tiles_per_shell;
 };
 

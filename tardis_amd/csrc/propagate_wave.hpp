@@ -124,6 +124,7 @@ struct __attribute__((aligned(16))) LaneSave {
 struct WaveSave {
     long long res_next, res_end;
     int exhausted, done;
+    int log_chunk, log_gen;  // volley queue (log_continue): the chunk of the line-visit log the wave was appending to, and the pool's generation
     // volley queue: the work counters of the wave's earlier launches (a call of thousands of launches would otherwise send
     // thousands x waves x 7 atomics to the same seven words: ~1 ms per launch)
     unsigned long long cnt[7];
@@ -154,6 +155,7 @@ struct WaveCold {
     unsigned *vq_items;
     unsigned *vq_count;
     int log_continue;
+    int log_gen;       // generation of the log's chunk pool (the host bumps it whenever it resets the pool): a chunk held from an earlier one is gone
     double *vq_jsave;  // [waves][2 * n_shells]: the waves' J / nu_bar partial sums between the launches of a volley-queue call
 };
 
@@ -707,7 +709,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     bool exhausted = false;  // wave-uniform: the chunk has no more packets to reserve
     long long res_next = 0, res_end = 0;  // wave-uniform: the block of packets this wave has reserved and not yet started
     int q_head = 0, q_tail = 0;  // wave-uniform: queue of prepared traces
-    unsigned log_used = 0;  // wave-uniform: records this wave has appended to its log region
+    unsigned log_used = 0;  // wave-uniform: records this wave has appended to the chunk of the line-visit log it holds
+    int log_chunk = -1;     // wave-uniform: that chunk (-1: none yet / the pool is empty)
+    bool logged_any = false;  // wave-uniform: this launch has logged something
     unsigned long long visits = 0;
     unsigned dbg_rounds = 0;  // wave-uniform profiling counter: sweep rounds (reported through counters[7])
     unsigned dbg_walk = 0;    // wave-uniform test counter (debug_flags 16384: jumps out of blocks longer than one window; 32768: jumps decided by the fp64 sums)
@@ -809,7 +813,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         asm volatile("" : "+v"(wave_idx));
         const WaveSave ws = gload(W->wsave + wave_idx);
         res_next = ws.res_next; res_end = ws.res_end; exhausted = ws.exhausted != 0;
-        if (W->log_continue) log_used = glob(W->log.region_count)[wave_idx];  // (volley queue: many short launches share one log buffer)
+        if (W->log_continue && ws.log_chunk >= 0 && ws.log_gen == W->log_gen) {  // (volley queue: many short launches share one log buffer)
+            log_chunk = ws.log_chunk;
+            log_used = glob(W->log.region_count)[(unsigned)log_chunk];
+        }
         if (ws.done) state = WS_DONE;
         else {
             const MC_G LaneSave &v = *glob(W->save + ((size_t)blockIdx.x * 64 + lane));  // (field by field: 360 bytes at once would not fit the registers)
@@ -852,7 +859,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         uint32_t *const seeded_states = W->seeded_states;
         const long long chunk_first = W->chunk_first, chunk_count = W->chunk_count;
         double *const jb = P.jblue_t, *const ed = P.edot_t;
-        const bool log_full = W->save && log.region_capacity > 0 && log_used + 64 > log.region_capacity && __ballot(state != WS_DONE) != 0ull;
+        // a pass appends at most 64 records: without room for them the wave takes the next chunk of the pool (one atomic per chunk)
+        bool log_full = false;
+        if (log.region_capacity > 0 && (log_chunk < 0 || log_used + 64 > log.region_capacity) && __ballot(state != WS_DONE) != 0ull) {
+            if (lane == 0 && log_chunk >= 0) glob(log.region_count)[log_chunk] = min(log_used, log.region_capacity);
+            unsigned c = 0;
+            if (lane == 0) c = gatomic_add_u32(log.pool_next, 1u);
+            c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+            log_used = 0;
+            if (c < (unsigned)log.n_regions) log_chunk = (int)c;
+            else { log_chunk = -1; log_full = W->save != nullptr; }  // the pool is empty: the epoch is over for this wave
+        }
         bool vq_stop = false;
         if (VPK && W->vq_items) {
             // volley queue: lanes whose round is with the tracer cannot go on in this launch; once (nearly) all others have
@@ -861,7 +878,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             const unsigned long long can = __ballot(state != WS_DONE && !(state == WS_VOLLEY && vq_fresh));
             vq_stop = waiting != 0ull && __popcll(can) <= H.vq_min_active;
         }
-        const bool drain_stop = W->drain_split && W->save && exhausted && res_next == res_end && log_used > 0 && __ballot(state != WS_DONE) != 0ull;
+        const bool drain_stop = W->drain_split && W->save && exhausted && res_next == res_end && logged_any && __ballot(state != WS_DONE) != 0ull;
         if (log_full || vq_stop || drain_stop) {
             // this wave's region of the line-visit log is full (or its lanes wait for the v-packet tracer): suspend the lanes as
             // they are (every lane is at the top of a pass: a swept trace waiting for its event, a lane sweep in progress, a
@@ -920,11 +937,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 type = code == 1 ? IT_BOUNDARY : (code == 2 ? IT_ESCATTERING : IT_LINE);
                 if (P.debug_flags & 1) n_visit = 0;
             }
-            // every wave appends to its own region of the log: no atomics, no empty slots
+            // every wave appends to the chunk it holds: no atomics, no empty slots
             const unsigned long long have = __ballot(n_visit > 0);
             if (have) {
                 const unsigned my = log_used + (unsigned)__popcll(have & ((1ull << lane) - 1ull));
                 log_used += (unsigned)__popcll(have);
+                logged_any = true;
                 if (n_visit > 0) {
                     LineVisitRecord rec;
                     const double inv_nu = 1.0 / p.nu;
@@ -932,11 +950,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     rec.c_jb = rec.c_e * inv_nu;
                     rec.idx0 = (unsigned)p.shell * (unsigned)L + (unsigned)start;
                     rec.n = (unsigned)n_visit;
-                    if (my < log.region_capacity) {
-                        const size_t slot = (size_t)blockIdx.x * log.region_capacity + my;
+                    if (log_chunk >= 0 && my < log.region_capacity) {
+                        const size_t slot = (size_t)(unsigned)log_chunk * log.region_capacity + my;
                         gstore(log.records + slot, rec);
                         glob(log.keys)[slot] = (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE);
-                    } else {  // region full (or no log): add the terms directly (slow path)
+                    } else {  // no log (or no chunk to be had and no way to suspend): add the terms directly (slow path)
                         for (int k = 0; k < n_visit; ++k) {
                             const double f = FULL ? 1.0 : glob(P.nu_line)[(unsigned)(start + k)];
                             gatomic_add_f64(&jb[rec.idx0 + (unsigned)k], rec.c_jb * f);
@@ -1785,7 +1803,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         TMC_SEC(6)
     }
 
-    if (lane == 0 && W->log.region_capacity > 0) glob(W->log.region_count)[blockIdx.x] = min(log_used, W->log.region_capacity);
+    if (lane == 0 && W->log.region_capacity > 0 && log_chunk >= 0) glob(W->log.region_count)[log_chunk] = min(log_used, W->log.region_capacity);
     const DeviceProblem *C = &W->D;
     const bool keep = suspended && W->vq_jsave != nullptr;  // volley queue: partial sums and counters stay with the wave
     if (W->vq_jsave) {
@@ -1809,6 +1827,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         if (W->wsave) {
             WaveSave ws;
             ws.res_next = res_next; ws.res_end = res_end; ws.exhausted = exhausted ? 1 : 0; ws.done = suspended ? 0 : 1;
+            ws.log_chunk = log_chunk; ws.log_gen = W->log_gen;
             if (W->vq_jsave && W->resume) {
                 const WaveSave old = gload(W->wsave + blockIdx.x);
 #pragma unroll

@@ -148,6 +148,7 @@ struct TardisMcContext {
     int walk_sector_packing = 1;  // compact walk tables: short blocks do not straddle 64-byte sectors (set before set_opacity; 0: packed at 16 bytes as in round 2)
     int vpacket_screening = -1;  // v-packet screening on the prefix sums of tau (tau_prefix.hpp): -1 automatic, 0 off, 1 on
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
+    long long log_chunk_records = 0;        // records per chunk of the line-visit log's pool (0: automatic, <= 4096; tests)
     long long log_capacity = 2500000000LL;  // upper bound of the line-visit records per epoch and buffer set of the wave kernel (24 B + 4 B + 4 B each)
     bool log_capacity_user = false;         // set through the log_capacity option (otherwise also bounded by the free device memory)
     // wave kernel: chunks alternate between two buffer sets / streams, so that seeding and the estimator passes of one
@@ -690,6 +691,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vq_tracer_waves_per_simd") ctx->vq_tracer_waves_per_simd = (int)std::max<long long>(1, std::min<long long>(value, 16));
     else if (n == "vq_min_items") ctx->vq_min_items = value;
     else if (n == "vq_min_active") ctx->vq_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
+    else if (n == "log_chunk_records") ctx->log_chunk_records = value <= 0 ? 0 : std::max<long long>(256, std::min<long long>(value, 1 << 20));
     else if (n == "walk_min_active") ctx->walk_min_active = (int)std::max<long long>(-1, std::min<long long>(value, 63));
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
     else if (n == "pipeline_chunks") {}  // (round 1: chunks on two streams; a call of the wave kernel now runs as epochs -- accepted, ignored)
@@ -1447,22 +1449,31 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                                                                   (unsigned long long)((double)n * ctx->log_budget_per_packet) + 64ull * (unsigned long long)waves + 65536ull);
             if (n_bins > mc::EST_MAX_BINS) cap = 0;  // too many tiles for the LDS histogram: the kernel adds its terms directly
             cap = std::min<unsigned long long>(cap, 0xfffffff0ull);
-            unsigned region_capacity = (unsigned)std::min<unsigned long long>(cap / (unsigned long long)waves, 0x7fffffffull);
-            if (region_capacity > 0 && region_capacity < 256) region_capacity = 256;  // (an epoch must make progress: >= 64 records per pass)
-            // (waves take packets dynamically, so any wave may fill its region before the others: every launch can suspend)
+            // The log is a pool of chunks the waves take one after the other (EstimatorLog, mc_device.hpp): chunks of up to 4096 records
+            // (~90 passes of a wave: one pool atomic per 7 ms), at least four per wave on average so that the pool runs dry for all
+            // waves at nearly the same time, never fewer than one per wave; a chunk holds >= 256 records (a pass appends up to 64).
+            unsigned region_capacity = 0;  // records per chunk
+            unsigned long long n_chunks = 0;
+            if (cap > 0) {
+                region_capacity = ctx->log_chunk_records > 0 ? (unsigned)ctx->log_chunk_records : 4096u;
+                while (region_capacity > 256 && (unsigned long long)region_capacity * 4ull * (unsigned long long)waves > cap) region_capacity >>= 1;
+                n_chunks = std::max<unsigned long long>(cap / region_capacity, (unsigned long long)waves);
+                if (n_chunks * region_capacity > 0xfffffff0ull) n_chunks = 0xfffffff0ull / region_capacity;
+            }
+            // (waves take chunks dynamically: every launch can suspend)
             const bool may_suspend = region_capacity > 0 || vq;
             // a second buffer set (the estimator passes of an epoch overlap the next epoch) only when the call may need several epochs
             // ... or splits off its drain (WaveCold::drain_split): worth a second launch once the call is long enough for a drain to form
             const bool want_split = ctx->drain_split && !vq && ctx->log_sets != 1 && region_capacity > 0 && n >= 64LL * waves * 4;
-            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((want_split || (region_capacity > 0 && (unsigned long long)region_capacity * waves < (unsigned long long)((double)n * ctx->log_budget_per_packet))) ? 2 : 1);
+            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((want_split || (region_capacity > 0 && (unsigned long long)region_capacity * n_chunks < (unsigned long long)((double)n * ctx->log_budget_per_packet))) ? 2 : 1);
             bool split_armed = want_split;
-            const size_t set_records = (size_t)std::max<unsigned long long>((unsigned long long)region_capacity * waves, 1);
+            const size_t set_records = (size_t)std::max<unsigned long long>((unsigned long long)region_capacity * n_chunks, 1);
             for (int b = 0; b < n_sets; ++b) {
                 HIP_TRY(ctx, ctx->log_records[b].ensure(set_records * sizeof(mc::LineVisitRecord)));
                 HIP_TRY(ctx, ctx->log_keys[b].ensure(set_records * sizeof(unsigned)));
                 HIP_TRY(ctx, ctx->log_sorted[b].ensure(set_records * sizeof(unsigned)));
                 HIP_TRY(ctx, ctx->log_bins[b].ensure((size_t)(4 * (n_bins + 2)) * sizeof(unsigned)));
-                HIP_TRY(ctx, ctx->log_cursor[b].ensure((size_t)waves * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->log_cursor[b].ensure((size_t)(n_chunks + 2) * sizeof(unsigned)));  // chunk counts | pool counter
             }
             if (n_sets == 2 && !ctx->stream2) {
                 int prio_lo = 0, prio_hi = 0;  // (the estimator passes' stream: highest priority, their workgroups are dispatched first)
@@ -1551,6 +1562,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             bool vq_on = vq;
             const long long vq_min_items = ctx->vq_min_items >= 0 ? ctx->vq_min_items : (long long)cus * 4 * 64 * 8;
             bool call_complete = n <= 0;
+            int log_gen = 0;  // (volley queue: the chunk pool of the shared log is reset after every run of the estimator passes)
             for (int epoch = 0; n > 0 && epoch < max_epochs; ++epoch) {
                 const int b = n_sets == 2 ? (epoch & 1) : 0;
                 hipStream_t es = n_sets == 2 ? ctx->stream2 : st;  // the estimator passes of an epoch run beside the next epoch
@@ -1565,11 +1577,12 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 lg.tiles_per_shell = tiles;
                 lg.records = ctx->log_records[b].as<mc::LineVisitRecord>();
                 lg.keys = ctx->log_keys[b].as<unsigned>();
-                lg.n_regions = waves;
+                lg.n_regions = (int)n_chunks;
                 lg.region_capacity = region_capacity;
                 lg.region_count = ctx->log_cursor[b].as<unsigned>();
+                lg.pool_next = lg.region_count + n_chunks;
                 // (volley queue: the launches of a call go on appending to the same log regions until one of them is full)
-                if (!vq || epoch == 0) HIP_TRY(ctx, hipMemsetAsync(lg.region_count, 0, (size_t)waves * sizeof(unsigned), st));
+                if (!vq || epoch == 0) HIP_TRY(ctx, hipMemsetAsync(lg.region_count, 0, (size_t)(n_chunks + 1) * sizeof(unsigned), st));
                 HIP_TRY(ctx, hipMemsetAsync(ctx->suspended_dev.p, 0, 4 * sizeof(unsigned), st));
                 if (vq) HIP_TRY(ctx, hipMemsetAsync(ctx->vq_count.p, 0, 2 * sizeof(unsigned), st));
                 mc::WaveCold &wc = ctx->wave_cold_host[epoch & 1];
@@ -1587,6 +1600,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 wc.vq_count = vq ? ctx->vq_count.as<unsigned>() : nullptr;
                 wc.vq_jsave = vq ? ctx->vq_jsave.as<double>() : nullptr;
                 wc.log_continue = vq ? 1 : 0;
+                wc.log_gen = log_gen;
                 mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + (epoch & 1);
                 HIP_TRY(ctx, store_value(st, wc_dev, wc));
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[2], st));
@@ -1617,7 +1631,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                         HIP_TRY(ctx, hipEventRecord(ctx->ev_post[0], st));
                         HIP_TRY(ctx, estimator_passes(lg, 0, st));
                         HIP_TRY(ctx, hipEventRecord(ctx->ev_post[1], st));
-                        HIP_TRY(ctx, hipMemsetAsync(lg.region_count, 0, (size_t)waves * sizeof(unsigned), st));
+                        HIP_TRY(ctx, hipMemsetAsync(lg.region_count, 0, (size_t)(n_chunks + 1) * sizeof(unsigned), st));
+                        ++log_gen;
                         HIP_TRY(ctx, hipEventSynchronize(ctx->ev_post[1]));
                         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_post[0], ctx->ev_post[1]));
                         ctx->sum_post_ms += ms;
