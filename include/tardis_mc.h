@@ -154,8 +154,10 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
  * never the automatic choice; falls back to 2/3 without v-packets and to 1 with a survival probability > 0),
  * "vq_min_items" (variant 4: switch the queue off for the rest of a call once a launch requests fewer v-packets; -1 automatic,
  * 0 never), "vq_min_active", "vq_oversubscribe", "vq_tracer_waves_per_simd" (variant 4 launch shape),
- * "lane_sweep_min_active" / "lane_sweep_max_steps" (when variant 3 leaves its sweep phase),
- * "walk_min_active" (macroatom walks are carried over to the next pass once this few lanes still walk; -1 never),
+ * "lane_sweep_min_active" / "lane_sweep_max_steps" (when variant 3 leaves its sweep phase; lane_sweep_min_active < 0: automatic --
+ * 8, or 12 where most macro-atom blocks are entered through hot sectors),
+ * "walk_min_active" (macroatom walks are carried over to the next pass once this few lanes still walk; -1 never, < -1 automatic:
+ * 8 / 12 likewise),
  * "log_capacity" (line-visit records per epoch and buffer set of the wave-owner kernel; a call that logs more runs as several
  * launches over one packet supply), "log_sets" (1: the estimator passes of an epoch run before the next
  * epoch instead of beside it), "chunk_packets" (packets per launch of the group kernel), "waves_per_simd", "group_size",

@@ -767,10 +767,10 @@ __device__ __forceinline__ int volley_group(const GroupArgs &P, const Packet &p,
                 atomic_add_f64(&P.vhist[idx], v_energy);
             }
             if (C->vlog_count) {
-                unsigned long long slot = atomicAdd(C->vlog_count, 1ull);
+                unsigned long long slot = gatomic_add_u64(C->vlog_count, 1ull);
                 if ((long long)slot < C->vlog_capacity) {
-                    C->vlog_packet[slot] = packet_index; C->vlog_seq[slot] = vseq + j;
-                    C->vlog_nu[slot] = v_nu; C->vlog_energy[slot] = v_energy; C->vlog_mu[slot] = v_mu0; C->vlog_r[slot] = p.r;
+                    glob(C->vlog_packet)[slot] = packet_index; glob(C->vlog_seq)[slot] = vseq + j;
+                    glob(C->vlog_nu)[slot] = v_nu; glob(C->vlog_energy)[slot] = v_energy; glob(C->vlog_mu)[slot] = v_mu0; glob(C->vlog_r)[slot] = p.r;
                 }
             }
         }
@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
                     const long long i = chunk_first + pkt;
                     asm volatile("" ::: "memory");  // keep the cold-argument loads inside this (rare) branch
                     const DeviceProblem *C = P.cold;
-                    p.r = C->r0[i]; p.mu = C->mu0[i]; p.nu = C->nu0[i]; p.energy = C->e0[i];
+                    p.r = glob(C->r0)[i]; p.mu = glob(C->mu0)[i]; p.nu = glob(C->nu0)[i]; p.energy = glob(C->e0)[i];
                     p.shell = 0; p.status = ST_IN_PROCESS;
                     if (TRACK && j == 0) {
                         const double nan = __builtin_nan("");
@@ -943,9 +943,9 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
                     if (verr) {
                         if (j == 0) {
                             const DeviceProblem *C2 = P.cold;
-                            atomicMin(&C2->first_error[0], chunk_first + pkt);
-                            C2->out_nu[chunk_first + pkt] = (double)verr;
-                            C2->out_e[chunk_first + pkt] = -99.0;
+                            gatomic_min_i64(&C2->first_error[0], chunk_first + pkt);
+                            glob(C2->out_nu)[chunk_first + pkt] = (double)verr;
+                            glob(C2->out_e)[chunk_first + pkt] = -99.0;
                         }
                         p.status = ST_EMITTED;
                     }
@@ -1029,9 +1029,9 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
             if (j == 0) {
                 asm volatile("" ::: "memory");
                 const DeviceProblem *C = P.cold;
-                atomicMin(&C->first_error[0], i);
-                C->out_nu[i] = (double)err;
-                C->out_e[i] = -99.0;
+                gatomic_min_i64(&C->first_error[0], i);
+                glob(C->out_nu)[i] = (double)err;
+                glob(C->out_e)[i] = -99.0;
             }
             p.status = ST_EMITTED;
         } else if (p.status != ST_IN_PROCESS) {
@@ -1040,15 +1040,15 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
             if (j == 0) {
                 asm volatile("" ::: "memory");  // keep the cold-argument loads inside this (rare) branch
                 const DeviceProblem *C = P.cold;
-                C->out_nu[i] = p.nu;
-                C->out_e[i] = (p.status == ST_REABSORBED) ? -p.energy : p.energy;
+                glob(C->out_nu)[i] = p.nu;
+                glob(C->out_e)[i] = (p.status == ST_REABSORBED) ? -p.energy : p.energy;
                 if (TRACK) {
-                    C->li_radius[i] = trk.radius; C->li_nu[i] = trk.nu; C->li_energy[i] = trk.energy;
-                    C->li_before_nu[i] = trk.before_nu; C->li_before_mu[i] = trk.before_mu; C->li_before_energy[i] = trk.before_energy;
-                    C->li_after_nu[i] = trk.after_nu; C->li_after_mu[i] = trk.after_mu; C->li_after_energy[i] = trk.after_energy;
-                    C->li_shell_id[i] = trk.shell_id; C->li_interaction_type[i] = trk.interaction_type;
-                    C->li_line_absorb_id[i] = trk.line_absorb_id; C->li_line_emit_id[i] = trk.line_emit_id;
-                    C->li_interactions_count[i] = trk.interactions_count;
+                    glob(C->li_radius)[i] = trk.radius; glob(C->li_nu)[i] = trk.nu; glob(C->li_energy)[i] = trk.energy;
+                    glob(C->li_before_nu)[i] = trk.before_nu; glob(C->li_before_mu)[i] = trk.before_mu; glob(C->li_before_energy)[i] = trk.before_energy;
+                    glob(C->li_after_nu)[i] = trk.after_nu; glob(C->li_after_mu)[i] = trk.after_mu; glob(C->li_after_energy)[i] = trk.after_energy;
+                    glob(C->li_shell_id)[i] = trk.shell_id; glob(C->li_interaction_type)[i] = trk.interaction_type;
+                    glob(C->li_line_absorb_id)[i] = trk.line_absorb_id; glob(C->li_line_emit_id)[i] = trk.line_emit_id;
+                    glob(C->li_interactions_count)[i] = trk.interactions_count;
                 }
             }
         }
@@ -1057,19 +1057,19 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
     __syncthreads();
     const DeviceProblem *C = P.cold;
     for (int s = threadIdx.x; s < P.n_shells; s += BLOCK) {
-        if (lds_J[s] != 0.0) atomic_add_f64(&C->J[s], lds_J[s]);
-        if (lds_nubar[s] != 0.0) atomic_add_f64(&C->nubar[s], lds_nubar[s]);
+        if (lds_J[s] != 0.0) gatomic_add_f64(&C->J[s], lds_J[s]);
+        if (lds_nubar[s] != 0.0) gatomic_add_f64(&C->nubar[s], lds_nubar[s]);
     }
     if (j == 0) {
-        atomicAdd(&C->counters[0], cn.visits);
-        atomicAdd(&C->counters[1], (unsigned long long)cn.events);
-        atomicAdd(&C->counters[2], (unsigned long long)cn.macro);
-        atomicAdd(&C->counters[5], draws_total);
+        gatomic_add_u64(&C->counters[0], cn.visits);
+        gatomic_add_u64(&C->counters[1], (unsigned long long)cn.events);
+        gatomic_add_u64(&C->counters[2], (unsigned long long)cn.macro);
+        gatomic_add_u64(&C->counters[5], draws_total);
     }
     if (VPK) {
-        if (vvisits) atomicAdd(&C->counters[3], (unsigned long long)vvisits);
-        if (vcount) atomicAdd(&C->counters[4], (unsigned long long)vcount);
-        if (vtraced) atomicAdd(&C->counters[7], vtraced);
+        if (vvisits) gatomic_add_u64(&C->counters[3], (unsigned long long)vvisits);
+        if (vcount) gatomic_add_u64(&C->counters[4], (unsigned long long)vcount);
+        if (vtraced) gatomic_add_u64(&C->counters[7], vtraced);
     }
 }
 

@@ -140,6 +140,7 @@ struct TardisMcContext {
     // launch geometry
     int variant = -1;  // 0: lane-per-packet kernel; 1: group-per-packet kernel; 2: wave-owner kernel, group sweeps; 3: wave-owner kernel, lane sweeps; -1: automatic
     bool prob_negative = false;  // a negative transition probability: the running sums are not monotone, no jump search
+    bool walk_min_active_user = false, ls_min_active_user = false;  // (set through the options: no automatic choice then)
     int walk_min_active = 8;  // compact macro-atom walk: carry the longest chains over to the next pass once this few lanes still walk (-1: never)
     int ls_min_active = 8, ls_max_steps = 1 << 30;  // lane sweeps: when to leave the sweep phase (propagate_wave.hpp)
     int blocks_per_cu = 16;
@@ -685,14 +686,20 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "walk_hot_min_mass_long") ctx->walk_hot_min_mass_long = (int)std::max<long long>(0, std::min<long long>(value, 1001));
     else if (n == "vpacket_screening") ctx->vpacket_screening = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "waves_per_simd") ctx->waves_per_simd = (int)value;
-    else if (n == "lane_sweep_min_active") ctx->ls_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
+    else if (n == "lane_sweep_min_active") {  // (< 0: the automatic choice again)
+        ctx->ls_min_active_user = value >= 0;
+        ctx->ls_min_active = value >= 0 ? (int)std::min<long long>(value, 63) : 8;
+    }
     else if (n == "lane_sweep_max_steps") ctx->ls_max_steps = (int)std::max<long long>(1, value);
     else if (n == "vq_oversubscribe") ctx->vq_oversubscribe = (int)std::max<long long>(1, std::min<long long>(value, 64));
     else if (n == "vq_tracer_waves_per_simd") ctx->vq_tracer_waves_per_simd = (int)std::max<long long>(1, std::min<long long>(value, 16));
     else if (n == "vq_min_items") ctx->vq_min_items = value;
     else if (n == "vq_min_active") ctx->vq_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "log_chunk_records") ctx->log_chunk_records = value <= 0 ? 0 : std::max<long long>(256, std::min<long long>(value, 1 << 20));
-    else if (n == "walk_min_active") ctx->walk_min_active = (int)std::max<long long>(-1, std::min<long long>(value, 63));
+    else if (n == "walk_min_active") {  // (-1: never carry a walk over; < -1: the automatic choice again)
+        ctx->walk_min_active_user = value >= -1;
+        ctx->walk_min_active = value >= -1 ? (int)std::min<long long>(value, 63) : 8;
+    }
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
     else if (n == "pipeline_chunks") {}  // (round 1: chunks on two streams; a call of the wave kernel now runs as epochs -- accepted, ignored)
     else if (n == "log_capacity") { ctx->log_capacity = std::max<long long>(0, value); ctx->log_capacity_user = true; }
@@ -1520,8 +1527,14 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
             hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
             hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
-            hot.ls_min_active = ctx->ls_min_active; hot.ls_max_steps = ctx->ls_max_steps;
-            hot.walk_min_active = ctx->walk_min_active; hot.vq_min_active = ctx->vq_min_active;
+            // cut-offs of the sweep / walk phases (lanes still busy when the wave moves on): 8 / 8 by default.  Where most blocks are
+            // entered through hot sectors the event phase is shorter and later cut-offs pay: 12 / 12 measured -2.5 % on the heavy-tailed
+            // configs[2] tables, +2 % on the uniform ones (profiles/r04_cutoffs.txt) -- hence only there, and never against an option
+            const bool mostly_hot = ctx->have_hot && 2 * ctx->n_hot_blocks > (long long)ctx->n_levels;
+            hot.ls_min_active = (!ctx->ls_min_active_user && mostly_hot) ? 12 : ctx->ls_min_active;
+            hot.ls_max_steps = ctx->ls_max_steps;
+            hot.walk_min_active = (!ctx->walk_min_active_user && mostly_hot) ? 12 : ctx->walk_min_active;
+            hot.vq_min_active = ctx->vq_min_active;
             hot.line_block = P.line_interaction_type != 0 ? P.line_block : nullptr;
             // binning + accumulation of one epoch's line-visit log (estimator_log.hpp)
             auto estimator_passes = [&](const mc::EstimatorLog &lg, int b, hipStream_t es) -> hipError_t {
