@@ -158,6 +158,9 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
  * 8, or 12 where most macro-atom blocks are entered through hot sectors),
  * "walk_min_active" (macroatom walks are carried over to the next pass once this few lanes still walk; -1 never, < -1 automatic:
  * 8 / 12 likewise),
+ * "log_tail_split" (1, the default: a call whose line-visit log fits one epoch is split where the drain of its longest-lived packets
+ * begins -- "log_tail_packets" (8) packets' worth of traces per lane before the estimated end -- so that the estimator passes over
+ * the bulk run beside the drain; 0 off), "log_chunk_records" (records per chunk of the log's pool, <= 4096 by default),
  * "log_capacity" (line-visit records per epoch and buffer set of the wave-owner kernel; a call that logs more runs as several
  * launches over one packet supply), "log_sets" (1: the estimator passes of an epoch run before the next
  * epoch instead of beside it), "chunk_packets" (packets per launch of the group kernel), "waves_per_simd", "group_size",

@@ -149,6 +149,8 @@ struct TardisMcContext {
     int walk_sector_packing = 1;  // compact walk tables: short blocks do not straddle 64-byte sectors (set before set_opacity; 0: packed at 16 bytes as in round 2)
     int vpacket_screening = -1;  // v-packet screening on the prefix sums of tau (tau_prefix.hpp): -1 automatic, 0 off, 1 on
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
+    int log_tail_packets = 8;               // tail split: packets' worth of traces a lane in flight still logs after the supply has run out
+    int log_tail_split = 1;                 // plan the epochs so that the last one holds only the drain of the call (see tardis_mc_propagate)
     long long log_chunk_records = 0;        // records per chunk of the line-visit log's pool (0: automatic, <= 4096; tests)
     long long log_capacity = 2500000000LL;  // upper bound of the line-visit records per epoch and buffer set of the wave kernel (24 B + 4 B + 4 B each)
     bool log_capacity_user = false;         // set through the log_capacity option (otherwise also bounded by the free device memory)
@@ -695,6 +697,8 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vq_tracer_waves_per_simd") ctx->vq_tracer_waves_per_simd = (int)std::max<long long>(1, std::min<long long>(value, 16));
     else if (n == "vq_min_items") ctx->vq_min_items = value;
     else if (n == "vq_min_active") ctx->vq_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
+    else if (n == "log_tail_split") ctx->log_tail_split = value ? 1 : 0;
+    else if (n == "log_tail_packets") ctx->log_tail_packets = (int)std::max<long long>(0, std::min<long long>(value, 1000));
     else if (n == "log_chunk_records") ctx->log_chunk_records = value <= 0 ? 0 : std::max<long long>(256, std::min<long long>(value, 1 << 20));
     else if (n == "walk_min_active") {  // (-1: never carry a walk over; < -1: the automatic choice again)
         ctx->walk_min_active_user = value >= -1;
@@ -1472,7 +1476,26 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             // a second buffer set (the estimator passes of an epoch overlap the next epoch) only when the call may need several epochs
             // ... or splits off its drain (WaveCold::drain_split): worth a second launch once the call is long enough for a drain to form
             const bool want_split = ctx->drain_split && !vq && ctx->log_sets != 1 && region_capacity > 0 && n >= 64LL * waves * 4;
-            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((want_split || (region_capacity > 0 && (unsigned long long)region_capacity * n_chunks < (unsigned long long)((double)n * ctx->log_budget_per_packet))) ? 2 : 1);
+            // Tail split: the last epoch of a call should hold only the DRAIN (the ~4 % of the records the longest-lived packets log
+            // after the packet supply has run out, on a mostly idle chip), so that the passes over everything before it run beside the
+            // drain and only the passes of the tail -- milliseconds -- are left for after the call.  The host knows the call's records
+            // from the last call's traces per packet and hands the second-to-last epoch a pool of exactly "what is left minus the
+            // tail"; with the chunk pool that epoch ends for all waves at once.  Also for calls whose log fits ONE epoch (their passes
+            // were not overlapped with anything before).  A wrong estimate only moves the boundary.
+            // (the tail: what the packets in flight when the supply runs out still log -- lanes x ~8 packets' worth of traces, the mean
+            // residual life of a heavy-tailed population; only for calls whose passes are worth a second launch: >= 5e8 records)
+            const double tail_records = (double)ctx->log_tail_packets * ctx->traces_per_packet * 64.0 * (double)waves;
+            // Measured (profiles/r04_tail_split.txt): calls whose log fits one epoch -3 ... -5 % (1e7 - 2e7 packets: their passes ran
+            // after the call before); calls of several epochs +0.5 % (their passes overlap the next epoch already, the extra launch
+            // costs) -- so only the former.
+            const bool one_epoch = (double)region_capacity * (double)n_chunks >= (double)n * ctx->traces_per_packet * 1.05;
+            const bool tail_plan = ctx->log_tail_split && !vq && ctx->log_sets != 1 && region_capacity > 0 && ctx->traces_per_packet > 0.0 && one_epoch &&
+                                   (double)n * ctx->traces_per_packet >= 5e8 && (double)n * ctx->traces_per_packet > 2.0 * tail_records;
+            // (the second buffer set is allocated as soon as a tail split MAY be planned -- the first call of a context has no estimate yet
+            // -- so that no later call of the same size allocates tens of GB in the middle of an iteration)
+            const bool tail_possible = ctx->log_tail_split && !vq && ctx->log_sets != 1 && region_capacity > 0 &&
+                                       (double)n * std::max(ctx->traces_per_packet, 16.0) >= 5e8;
+            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((tail_plan || tail_possible || want_split || (region_capacity > 0 && (unsigned long long)region_capacity * n_chunks < (unsigned long long)((double)n * ctx->log_budget_per_packet))) ? 2 : 1);
             bool split_armed = want_split;
             const size_t set_records = (size_t)std::max<unsigned long long>((unsigned long long)region_capacity * n_chunks, 1);
             for (int b = 0; b < n_sets; ++b) {
@@ -1576,6 +1599,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const long long vq_min_items = ctx->vq_min_items >= 0 ? ctx->vq_min_items : (long long)cus * 4 * 64 * 8;
             bool call_complete = n <= 0;
             int log_gen = 0;  // (volley queue: the chunk pool of the shared log is reset after every run of the estimator passes)
+            const double records_est = (double)n * ctx->traces_per_packet;  // (tail split: what the call will log, by the last call's measure)
+            double records_done = 0.0;
             for (int epoch = 0; n > 0 && epoch < max_epochs; ++epoch) {
                 const int b = n_sets == 2 ? (epoch & 1) : 0;
                 hipStream_t es = n_sets == 2 ? ctx->stream2 : st;  // the estimator passes of an epoch run beside the next epoch
@@ -1590,7 +1615,14 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 lg.tiles_per_shell = tiles;
                 lg.records = ctx->log_records[b].as<mc::LineVisitRecord>();
                 lg.keys = ctx->log_keys[b].as<unsigned>();
-                lg.n_regions = (int)n_chunks;
+                unsigned long long pool_chunks = n_chunks;
+                if (tail_plan) {
+                    const double bulk = records_est - records_done - tail_records;  // what is left before the tail
+                    if (bulk > 0.0 && bulk <= (double)n_chunks * (double)region_capacity)
+                        pool_chunks = std::min<unsigned long long>(n_chunks, std::max<unsigned long long>((unsigned long long)waves,
+                                                                                                           (unsigned long long)(bulk / (double)region_capacity) + 1ull));
+                }
+                lg.n_regions = (int)pool_chunks;
                 lg.region_capacity = region_capacity;
                 lg.region_count = ctx->log_cursor[b].as<unsigned>();
                 lg.pool_next = lg.region_count + n_chunks;
@@ -1630,6 +1662,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 if (may_suspend) {  // (read back before the estimator passes are queued: the host learns early whether another epoch follows)
                     HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host, ctx->suspended_dev.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
                     if (vq) HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host + 4, ctx->vq_count.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    if (region_capacity > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host + 6, lg.pool_next, sizeof(unsigned), hipMemcpyDeviceToHost, st));
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4], st));
                 }
                 ctx->launches += 1;
@@ -1668,6 +1701,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 ctx->sum_prop_ms += ms;
                 ctx->prop_pending = false;
                 if (*ctx->suspended_host == 0) { call_complete = true; break; }
+                records_done += (double)std::min<unsigned long long>((unsigned long long)ctx->suspended_host[6], pool_chunks) * (double)region_capacity;
                 if (ctx->suspended_host[2] > 0) split_armed = false;  // (the drain has been split off: the next launch runs to the end)
             }
             if (!call_complete)  // (packets would be left suspended in lane_save, outputs and estimators silently incomplete)
