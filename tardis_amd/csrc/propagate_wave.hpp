@@ -661,7 +661,10 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
     return 0;
 }
 
-template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false>
+// XWALK: with the macro-atom walks on the fp64 running sums compiled in (the cooperative group scan and the per-lane search: what the
+// wave kernel runs when the compact walk tables are not used -- debug flags 128 / 8192, cross-checks); the production instantiations
+// leave them out: ~1 100 instructions and two inlined MT19937 refills less.
+template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false, bool XWALK = true>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3 : 4, VPK ? 3 : 4))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1141,7 +1144,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 reinterpret_cast<int2 *>(sh.rcp_chi)[lane] = make_int2(mb0, redo ? (mb1 | WALK_REDO) : mb1);
                 if (redo) sh.tau_event[lane] = event;
             }
-        } else if (P.line_interaction_type == 2 && !(P.debug_flags & 128)) {  // (flag 128: the per-lane search below, for tests)
+        } else if (XWALK && P.line_interaction_type == 2 && !(P.debug_flags & 128)) {  // (flag 128: the per-lane search below, for tests)
             // macroatom mode (long chains of jumps, and a wave waits for its longest chain: one coalesced round trip per jump): the wave's G-lane groups scan the blocks, G
             // probabilities per coalesced load, accumulated in the reference's serial order (macro_atom_group() of the
             // group kernel).  The work items and results live in LDS that the trace parameters do not need right now.
@@ -1244,7 +1247,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         // downbranch (one jump over a short block)
         bool have_emit_nu = P.cum16 != nullptr && emit >= 0 && !carried;  // (the compact walk brought the frequency along)
         double emit_nu = emit_nu_walk;
-        {
+        if (XWALK) {
             bool searching = false;  // the first eight entries did not decide this lane's jump: 4-ary search in [lo, hi)
             int lo = 0, hi = 0;      // cum[j] <= event for all block entries j < lo; hi == mb1 or cum[hi] > event
             double event = 0.0;

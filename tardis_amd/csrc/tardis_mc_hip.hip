@@ -1422,14 +1422,22 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const int wave_waves_per_cu = std::max(1, std::min(ctx->waves_per_simd > 0 ? 4 * ctx->waves_per_simd : 16, (int)((160 * 1024) / wave_lds)));
             using WaveKernelFn = void (*)(mc::WaveHot, const mc::WaveCold *);
             WaveKernelFn kw = nullptr;
-#define TMC_PICKW2(G_, V_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_, V_> : mc::propagate_wave_kernel<true, false, G_, V_>) \
-                                 : (trk ? mc::propagate_wave_kernel<false, true, G_, V_> : mc::propagate_wave_kernel<false, false, G_, V_>))
+            // (XW: the instantiations with the macro-atom walks on the fp64 running sums compiled in -- only launched when the compact
+            // walk tables are not used: debug flags 128 / 8192, tables too large; the production ones are 22 % shorter without them)
+#define TMC_PICKW3(G_, V_, X_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_, V_, false, X_> : mc::propagate_wave_kernel<true, false, G_, V_, false, X_>) \
+                                     : (trk ? mc::propagate_wave_kernel<false, true, G_, V_, false, X_> : mc::propagate_wave_kernel<false, false, G_, V_, false, X_>))
+#define TMC_PICKW2(G_, V_) (xwalk ? TMC_PICKW3(G_, V_, true) : TMC_PICKW3(G_, V_, false))
 #define TMC_PICKW(G_) (vpk ? TMC_PICKW2(G_, true) : TMC_PICKW2(G_, false))
-#define TMC_PICKLS(G_, V_) (trk ? mc::propagate_wave_kernel<false, true, G_, V_, true> : mc::propagate_wave_kernel<false, false, G_, V_, true>)
-            // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel)
+#define TMC_PICKLS2(V_, X_) (trk ? mc::propagate_wave_kernel<false, true, 16, V_, true, X_> : mc::propagate_wave_kernel<false, false, 16, V_, true, X_>)
+#define TMC_PICKLS(V_) (xwalk ? TMC_PICKLS2(V_, true) : TMC_PICKLS2(V_, false))
+            const bool xwalk = (c.line_interaction_type != 0 && !compact_walk) || (ctx->debug_flags & 1048576) != 0;  // (flag 1048576: the long instantiations, for A/B)
+            // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel; the lane-sweep
+            // instantiations only use it in the cross-check walks: one width)
             const int GW = ctx->group_size ? ctx->group_size : (ctx->n_lines <= 100000 ? 8 : 16);
-            if (lane_sweep) kw = (GW == 16) ? (vpk ? TMC_PICKLS(16, true) : TMC_PICKLS(16, false)) : (vpk ? TMC_PICKLS(8, true) : TMC_PICKLS(8, false));
+            if (lane_sweep) kw = vpk ? TMC_PICKLS(true) : TMC_PICKLS(false);
             else kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
+#undef TMC_PICKLS2
+#undef TMC_PICKW3
 #undef TMC_PICKLS
 #undef TMC_PICKW2
 #undef TMC_PICKW

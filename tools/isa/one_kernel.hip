@@ -14,4 +14,7 @@
 #define K_VPK false
 #define K_LS true
 #endif
-template __global__ void mc::propagate_wave_kernel<K_FULL, K_TRACK, K_G, K_VPK, K_LS>(mc::WaveHot, const mc::WaveCold *);
+#ifndef K_XWALK
+#define K_XWALK true
+#endif
+template __global__ void mc::propagate_wave_kernel<K_FULL, K_TRACK, K_G, K_VPK, K_LS, K_XWALK>(mc::WaveHot, const mc::WaveCold *);
