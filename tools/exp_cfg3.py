@@ -33,7 +33,7 @@ eng = Engine(0)
 eng.set_geometry(prob.geometry, prob.time_explosion)
 eng.set_opacity(prob.opacity_state)
 eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
-defaults = {"log_tail_split": 1, "log_tail_packets": 8, "variant": -1, "debug_flags": 0, "group_size": 0, "lane_sweep_min_active": -1, "walk_min_active": -2, "lane_sweep_max_steps": 1 << 30, "waves_per_simd": 4,
+defaults = {"est_pipeline": int(os.environ.get("EXP_EST_PIPELINE", 0)), "log_tail_split": 1, "log_tail_packets": 8, "variant": -1, "debug_flags": 0, "group_size": 0, "lane_sweep_min_active": -1, "walk_min_active": -2, "lane_sweep_max_steps": 1 << 30, "waves_per_simd": 4,
             "track_last_interaction": 1, "walk_hot": -1, "walk_hot_min_mass": int(os.environ.get("EXP_HOT_SHORT", 800)),
             "walk_hot_min_mass_long": int(os.environ.get("EXP_HOT_LONG", 400)), "walk_sector_packing": 1}
 TABLE_OPTIONS = ("walk_hot", "walk_hot_min_mass", "walk_hot_min_mass_long", "walk_sector_packing")  # take effect in set_opacity
@@ -58,10 +58,16 @@ for e in exps:
         best = min(best, eng.last_propagate_ms())
     kt = eng.last_kernel_times()
     c = eng.last_counters()
+    est = ""
+    if os.environ.get("EXP_EST_SUMS"):  # the line estimators themselves: sums over all (line, shell) cells and an index-weighted sum
+        import numpy as np
+        r = eng.get_results(track_last_interaction=False, want_packet_outputs=False)
+        wgt = np.arange(r.j_blue_estimator.size, dtype=np.float64).reshape(r.j_blue_estimator.shape) % 977.0
+        est = f"  jb {r.j_blue_estimator.sum():.12e} {(r.j_blue_estimator * wgt).sum():.12e} ed {r.edotlu_estimator.sum():.12e} {(r.edotlu_estimator * wgt).sum():.12e}"
     sig = (c["line_visits"], c["events"], c["macro_transitions"], c["rng_draws"])
     if ref is None:
         ref = sig
     vp = f" vp/pkt {c['vpackets'] / P:7.1f} vpvis/vp {c['vpacket_line_visits'] / max(c['vpackets'], 1):7.1f}" if c.get("vpackets") else ""
     print(f"{e:60s} {best:9.2f} ms  {P / best / 1e3:7.2f} Mpkt/s  propagate {kt['propagate_ms']:8.2f} ms x{kt['launches']}  "
-          f"est {kt['estimator_ms']:7.2f} ms  counters {'same' if sig == ref else 'DIFFER ' + str(sig)}  c7={c['reserved']}{vp}", flush=True)
+          f"est {kt['estimator_ms']:7.2f} ms  counters {'same' if sig == ref else 'DIFFER ' + str(sig)}  c7={c['reserved']}{vp}{est}", flush=True)
 eng.close()
