@@ -161,6 +161,10 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
  * "log_tail_split" (1, the default: a call whose line-visit log fits one epoch is split where the drain of its longest-lived packets
  * begins -- "log_tail_packets" (8) packets' worth of traces per lane before the estimated end -- so that the estimator passes over
  * the bulk run beside the drain; 0 off), "log_chunk_records" (records per chunk of the log's pool, <= 4096 by default),
+ * "est_pipeline" (how an epoch's line-visit log becomes j_blue / Edotlu: 1, the default: the records are partitioned by shell and then
+ * by (shell, 2048-line tile) in two LDS-staged passes and added up in order, csrc/estimator_partition.hpp; 0: an index of the records is
+ * counting-sorted and the records are fetched through it, csrc/estimator_log.hpp -- also what runs for line lists of more than 2e6 lines
+ * or more than 1024 shells), "est_accumulate" (est_pipeline 0 only: 1 block sums, 0 one LDS add per line visit),
  * "log_capacity" (line-visit records per epoch and buffer set of the wave-owner kernel; a call that logs more runs as several
  * launches over one packet supply), "log_sets" (1: the estimator passes of an epoch run before the next
  * epoch instead of beside it), "chunk_packets" (packets per launch of the group kernel), "waves_per_simd", "group_size",

@@ -15,6 +15,9 @@
 //   accumulate_kernel  -- per bin slice: the tile's j_blue/Edotlu live in LDS, every record of the slice adds its two
 //                         constants over its range of lines with LDS atomics; the tile is multiplied by nu_line and
 //                         added to the global arrays once.
+// Round 4: the default is now the pipeline of estimator_partition.hpp (the records themselves are grouped by bin in two passes, then
+// accumulate_blocks_kernel below reads them in order); the index pipeline above stays as option "est_pipeline" 0 and for shapes the
+// partition kernel's local buckets do not cover.
 // The sums agree with the serial reference's to rounding: a different order of the same terms (as with atomics), each term
 // within ~1e-14 of the reference's (tests/test_lane_sweep_bounds.py).
 #pragma once
@@ -25,7 +28,7 @@
 namespace mc {
 
 constexpr int EST_TILE = 2048;       // lines per LDS tile (2 x 16 KiB)
-constexpr int EST_SLICE = 16384;     // records per accumulate workgroup pass
+constexpr int EST_SLICE = 65536;     // records per accumulate workgroup pass
 constexpr int EST_APRON = 256;       // lines past the end of a tile that are still accumulated in LDS (traces start in
                                      // their bin's tile and may run on into the next one)
 constexpr int EST_MAX_BINS = 36864;  // largest LDS histogram of the binning kernels (dynamic LDS, 4 B per bin = 144 KiB)
@@ -220,6 +223,146 @@ __global__ void __launch_bounds__(64 * ACC_WAVES) accumulate_kernel(const LineVi
             const double f = FULL ? 1.0 : nu_line[tile_idx0 - row + k];
             if (tile_jb[k] != 0.0) atomic_add_f64(&jblue_t[tile_idx0 + k], tile_jb[k] * f);
             if (tile_ed[k] != 0.0) atomic_add_f64(&edot_t[tile_idx0 + k], tile_ed[k] * f);
+        }
+        __syncthreads();
+    }
+}
+
+// accumulate_kernel with BLOCK SUMS (round 4).  On the configs[2] table shape a trace passes 41 lines on average (3300 line visits
+// per packet, 80 records): two ds_add_f64 per visit cost 11 LDS cycles per wave instruction each, and ~12 vector instructions per
+// record are what a SIMD (one VALU issue per four cycles) has time for.  A record adds the SAME two constants to every line of
+// [a, a + n): here the lines up to the next 8-line boundary and those after the last one are added one by one as before, but every
+// aligned block of 8 lines in between gets ONE add, into a per-block accumulator behind the tile; when the tile is flushed a line's sum
+// is its own accumulator plus its block's.  41 visits become ~11 adds.  Nothing is subtracted anywhere: the terms of a line's sum are
+// the reference's, associated differently (as they already are with atomics); a line nobody visited stays exactly 0.
+// Measured (profiles/r04_estimator_partition.txt, 1.6e9 records): 35.7 ms reading the records in order (DIRECT), 78 ms through the sorted
+// index (bound by the random 24-byte fetches; accumulate_kernel: 85 ms).
+constexpr int ACCB_WAVES = 16;                           // two workgroups per CU (72 KB of LDS each)
+constexpr int ACCB_TILE = EST_TILE + EST_APRON;          // lines in LDS
+constexpr int ACCB_BLOCKS = ACCB_TILE / 8;
+constexpr int ACCB_LONG = 255;                           // longer records are walked by the whole wave (<= 7 + 31 + 7 items otherwise)
+constexpr int ACCB_PASSES = 48;                          // >= 45 = the items of 64 records of ACCB_LONG lines / 64
+static_assert(ACCB_TILE % 8 == 0, "whole blocks");
+
+// DIRECT: the records are grouped by bin already (estimator_partition.hpp): slice r reads records[r], no index.
+template <bool FULL, bool DIRECT>
+__global__ void __launch_bounds__(64 * ACCB_WAVES, 8) accumulate_blocks_kernel(const LineVisitRecord *__restrict__ records,
+                                                                               const unsigned *__restrict__ sorted_index,
+                                                                               const unsigned *__restrict__ bin_start,
+                                                                               const unsigned *__restrict__ slice_start, int n_bins,
+                                                                               int tiles_per_shell, int n_lines, const double *__restrict__ nu_line,
+                                                                               double *__restrict__ jblue_t, double *__restrict__ edot_t)
+{
+    __builtin_amdgcn_s_setprio(3);
+    // accumulators: [0, ACCB_TILE) the lines of the tile, [ACCB_TILE, ACCB_TILE + ACCB_BLOCKS) its aligned 8-line blocks
+    __shared__ double acc_jb[ACCB_TILE + ACCB_BLOCKS], acc_ed[ACCB_TILE + ACCB_BLOCKS];
+    // staged records: the constants; a | h << 12 | b << 15 (first line relative to the tile, lines before the first boundary, whole
+    // blocks); the record's first item in the batch
+    struct __attribute__((aligned(8))) Staged { double c_e, c_jb; unsigned ahb, first; };
+    __shared__ Staged staged[ACCB_WAVES][64];
+    __shared__ unsigned long long starts[ACCB_WAVES][ACCB_PASSES];
+    const unsigned n_slices = slice_start[n_bins];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long le_mask = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    for (unsigned slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+        int lo = 0, hi = n_bins;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (slice_start[mid] <= slice) lo = mid; else hi = mid;
+        }
+        const int bin = lo;
+        const unsigned rec_first = bin_start[bin] + (slice - slice_start[bin]) * EST_SLICE;
+        const unsigned rec_last = min(bin_start[bin + 1], rec_first + EST_SLICE);
+        const int shell = bin / tiles_per_shell, tile = bin - shell * tiles_per_shell;
+        const unsigned row = (unsigned)shell * (unsigned)n_lines;
+        const unsigned tile_idx0 = row + (unsigned)tile * EST_TILE;
+        const unsigned tile_len = min((unsigned)ACCB_TILE, (unsigned)n_lines - (unsigned)tile * EST_TILE);  // never past the shell's row
+        for (int k = threadIdx.x; k < ACCB_TILE + ACCB_BLOCKS; k += 64 * ACCB_WAVES) { acc_jb[k] = 0.0; acc_ed[k] = 0.0; }
+        __syncthreads();
+        auto far_line = [&](unsigned o, double c_jb, double c_e) {  // a line past the LDS tile (o: relative to the tile)
+            const double f = FULL ? 1.0 : nu_line[tile_idx0 - row + o];
+            atomic_add_f64(&jblue_t[tile_idx0 + o], c_jb * f);
+            atomic_add_f64(&edot_t[tile_idx0 + o], c_e * f);
+        };
+        // item j of a record {a, h, b}: the h lines before its first 8-line boundary, its b whole blocks, the lines after the last boundary
+        // (a record never runs past its shell's row, so a block it covers exists in full)
+        auto add_item = [&](unsigned a, unsigned h, unsigned b, unsigned j, double c_jb, double c_e) {
+            const unsigned jh = j - h;                                  // (wraps for j < h: not a block then)
+            const bool is_blk = jh < b;
+            const unsigned line = a + j + (j >= h + b ? 7u * b : 0u);   // after the blocks: a + h + 8 b + (j - h - b)
+            const unsigned blk_line = a + h + 8u * jh;                  // first line of block jh
+            const unsigned idx = is_blk ? (unsigned)ACCB_TILE + (blk_line >> 3) : line;
+            const bool in_tile = is_blk ? blk_line + 8u <= tile_len : line < tile_len;
+            if (in_tile) {
+                atomicAdd(&acc_jb[idx], c_jb);
+                atomicAdd(&acc_ed[idx], c_e);
+            } else if (is_blk) {
+                for (unsigned k = 0; k < 8u; ++k) {
+                    if (blk_line + k < tile_len) { atomicAdd(&acc_jb[blk_line + k], c_jb); atomicAdd(&acc_ed[blk_line + k], c_e); }
+                    else far_line(blk_line + k, c_jb, c_e);
+                }
+            } else far_line(line, c_jb, c_e);
+        };
+        auto fetch = [&](unsigned r) {
+            LineVisitRecord rec;
+            rec.c_e = rec.c_jb = 0.0; rec.idx0 = tile_idx0; rec.n = 0;
+            if (r < rec_last) rec = records[DIRECT ? r : sorted_index[r]];
+            return rec;
+        };
+        const unsigned stride = 64 * ACCB_WAVES;
+        unsigned base = rec_first + (unsigned)w * 64;
+        LineVisitRecord next = fetch(base + (unsigned)lane);  // (32 waves per CU: one batch ahead is enough)
+        for (; base < rec_last; base += stride) {
+            const LineVisitRecord rec = next;
+            next = fetch(base + stride + (unsigned)lane);
+            const unsigned n_all = rec.n, a = rec.idx0 - tile_idx0;  // a < EST_TILE
+            const unsigned h = min(n_all, (8u - (a & 7u)) & 7u), b = (n_all - h) >> 3, tl = (n_all - h) & 7u;
+            const unsigned m = n_all > (unsigned)ACCB_LONG ? 0u : h + b + tl;  // (<= 45 items; long records are handled below)
+            unsigned incl = m;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)incl, off);
+                if (lane >= off) incl += up;
+            }
+            const unsigned excl = incl - m;
+            const unsigned total = (unsigned)__shfl((int)incl, 63);
+            const unsigned n_pass = (total + 63) >> 6;  // <= 45
+            if (lane < ACCB_PASSES) starts[w][lane] = 0ull;
+            if (m) {  // staged in compacted order: the q-th record that starts is the q-th staged one
+                const int pos = __popcll(__ballot(true) & ((1ull << lane) - 1ull));
+                Staged st;
+                st.c_e = rec.c_e; st.c_jb = rec.c_jb; st.ahb = a | (h << 12) | (b << 15); st.first = excl;
+                staged[w][pos] = st;
+                atomicOr(&starts[w][excl >> 6], 1ull << (excl & 63));
+            }
+            unsigned rec_base = 0;  // records started before this pass (wave-uniform)
+            for (unsigned i = 0; i < n_pass; ++i) {
+                const unsigned long long mk = starts[w][i];
+                const unsigned t = (i << 6) + (unsigned)lane;
+                if (t < total) {
+                    const unsigned q = rec_base + (unsigned)__popcll(mk & le_mask) - 1u;
+                    const Staged st = staged[w][q];
+                    add_item(st.ahb & 0xfffu, (st.ahb >> 12) & 7u, st.ahb >> 15, t - st.first, st.c_jb, st.c_e);
+                }
+                rec_base += (unsigned)__popcll(mk);
+            }
+            // long records: the whole wave walks the items of one record at a time
+            unsigned long long longs = __ballot(n_all > (unsigned)ACCB_LONG);
+            while (longs) {
+                const int q = __builtin_ctzll(longs);
+                longs &= longs - 1;
+                const unsigned q_a = (unsigned)__shfl((int)a, q), q_h = (unsigned)__shfl((int)h, q), q_b = (unsigned)__shfl((int)b, q);
+                const unsigned q_m = q_h + q_b + (unsigned)__shfl((int)tl, q);
+                const double l_ce = __shfl(rec.c_e, q), l_cjb = __shfl(rec.c_jb, q);
+                for (unsigned k = lane; k < q_m; k += 64) add_item(q_a, q_h, q_b, k, l_cjb, l_ce);
+            }
+        }
+        __syncthreads();
+        for (unsigned k = threadIdx.x; k < tile_len; k += 64 * ACCB_WAVES) {
+            const double f = FULL ? 1.0 : nu_line[tile_idx0 - row + k];
+            const double v_jb = acc_jb[k] + acc_jb[ACCB_TILE + (k >> 3)], v_ed = acc_ed[k] + acc_ed[ACCB_TILE + (k >> 3)];
+            if (v_jb != 0.0) atomic_add_f64(&jblue_t[tile_idx0 + k], v_jb * f);
+            if (v_ed != 0.0) atomic_add_f64(&edot_t[tile_idx0 + k], v_ed * f);
         }
         __syncthreads();
     }

@@ -21,6 +21,7 @@
 #include "propagate_lane.hpp"
 #include "propagate_group.hpp"
 #include "estimator_log.hpp"
+#include "estimator_partition.hpp"
 #include "propagate_wave.hpp"
 #include "packet_source.hpp"
 #include "formal_integral.hpp"
@@ -151,6 +152,9 @@ struct TardisMcContext {
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
     int log_tail_packets = 8;               // tail split: packets' worth of traces a lane in flight still logs after the supply has run out
     int log_tail_split = 1;                 // plan the epochs so that the last one holds only the drain of the call (see tardis_mc_propagate)
+    int est_accumulate = 1;                 // accumulate kernel of the index pipeline: 1 with block sums (accumulate_blocks_kernel), 0 one add per line visit (accumulate_kernel)
+    int est_pipeline = 1;                   // line-estimator passes: 1 two-level partition of the records (estimator_partition.hpp), 0 index sort + gather (estimator_log.hpp)
+    DevBuf log_part;                        // est_pipeline 1: the scratch copy of one epoch's records, shared by both buffer sets
     long long log_chunk_records = 0;        // records per chunk of the line-visit log's pool (0: automatic, <= 4096; tests)
     long long log_capacity = 2500000000LL;  // upper bound of the line-visit records per epoch and buffer set of the wave kernel (24 B + 4 B + 4 B each)
     bool log_capacity_user = false;         // set through the log_capacity option (otherwise also bounded by the free device memory)
@@ -626,6 +630,7 @@ int tardis_mc_create(int device_id, TardisMcContext **out_ctx)
     if (const char *v = getenv("TARDIS_MC_VARIANT")) ctx->variant = atoi(v);
     if (const char *v = getenv("TARDIS_MC_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, atoi(v));
     if (const char *v = getenv("TARDIS_MC_DEBUG_FLAGS")) ctx->debug_flags = atoi(v);
+    if (const char *v = getenv("TARDIS_MC_EST_PIPELINE")) ctx->est_pipeline = atoi(v) ? 1 : 0;
     if (const char *v = getenv("TARDIS_MC_EST_COPIES")) ctx->est_copies = std::max(1, std::min(8, atoi(v)));
     *out_ctx = ctx;
     return TARDIS_MC_OK;
@@ -646,6 +651,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
         ctx->log_records[b].release(); ctx->log_keys[b].release(); ctx->log_cursor[b].release(); ctx->log_bins[b].release();
         ctx->log_sorted[b].release();
     }
+    ctx->log_part.release();
     ctx->wave_cold_dev.release();
     ctx->seed_chk[0].release(); ctx->seed_chk[1].release(); ctx->vp_scratch[0].release(); ctx->vp_scratch[1].release();
     for (auto &b : ctx->li_f64) b.release();
@@ -698,6 +704,8 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vq_min_items") ctx->vq_min_items = value;
     else if (n == "vq_min_active") ctx->vq_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "log_tail_split") ctx->log_tail_split = value ? 1 : 0;
+    else if (n == "est_pipeline") ctx->est_pipeline = value ? 1 : 0;
+    else if (n == "est_accumulate") ctx->est_accumulate = value ? 1 : 0;
     else if (n == "log_tail_packets") ctx->log_tail_packets = (int)std::max<long long>(0, std::min<long long>(value, 1000));
     else if (n == "log_chunk_records") ctx->log_chunk_records = value <= 0 ? 0 : std::max<long long>(256, std::min<long long>(value, 1 << 20));
     else if (n == "walk_min_active") {  // (-1: never carry a walk over; < -1: the automatic choice again)
@@ -1453,6 +1461,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             if (1.1 * ctx->traces_per_packet > ctx->log_budget_per_packet) ctx->log_budget_per_packet = 1.3 * ctx->traces_per_packet;
             const int tiles = std::max((ctx->n_lines + mc::EST_TILE - 1) / mc::EST_TILE, 1);
             const int n_bins = ctx->n_shells * tiles;
+            // est_pipeline 1 (estimator_partition.hpp): the records are grouped by shell, then by bin; needs a shell's bins and all shells
+            // to fit the partition kernel's local buckets
+            const bool partition = ctx->est_pipeline == 1 && tiles <= mc::PART_LOCAL_BUCKETS && ctx->n_shells <= mc::PART_LOCAL_BUCKETS;
             long long log_capacity = ctx->log_capacity;
             if (!ctx->log_capacity_user) {
                 // (fewer, longer epochs are faster -- 25.8 vs 24.5 Mpkt/s at 1e8 packets with 2.5e9 instead of 1.5e9 records per set
@@ -1460,8 +1471,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 size_t free_b = 0, total_b = 0;
                 if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                     const double have = (double)(ctx->log_records[0].cap + ctx->log_records[1].cap + ctx->log_keys[0].cap + ctx->log_keys[1].cap +
-                                                 ctx->log_sorted[0].cap + ctx->log_sorted[1].cap);
-                    log_capacity = std::min<long long>(log_capacity, (long long)(0.6 * ((double)free_b + have) / 64.0));
+                                                 ctx->log_sorted[0].cap + ctx->log_sorted[1].cap + ctx->log_part.cap);
+                    // (bytes per record of capacity: two sets of 24 + 4 and an index of 4 each, or the shared scratch copy of 24)
+                    log_capacity = std::min<long long>(log_capacity, (long long)(0.6 * ((double)free_b + have) / (partition ? 80.0 : 64.0)));
                 }
             }
             unsigned long long cap = std::min<unsigned long long>((unsigned long long)log_capacity,
@@ -1509,10 +1521,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             for (int b = 0; b < n_sets; ++b) {
                 HIP_TRY(ctx, ctx->log_records[b].ensure(set_records * sizeof(mc::LineVisitRecord)));
                 HIP_TRY(ctx, ctx->log_keys[b].ensure(set_records * sizeof(unsigned)));
-                HIP_TRY(ctx, ctx->log_sorted[b].ensure(set_records * sizeof(unsigned)));
-                HIP_TRY(ctx, ctx->log_bins[b].ensure((size_t)(4 * (n_bins + 2)) * sizeof(unsigned)));
+                if (!partition) HIP_TRY(ctx, ctx->log_sorted[b].ensure(set_records * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->log_bins[b].ensure((size_t)(4 * (n_bins + 2) + ctx->n_shells + 2) * sizeof(unsigned)));
                 HIP_TRY(ctx, ctx->log_cursor[b].ensure((size_t)(n_chunks + 2) * sizeof(unsigned)));  // chunk counts | pool counter
             }
+            if (partition) HIP_TRY(ctx, ctx->log_part.ensure(set_records * sizeof(mc::LineVisitRecord)));
             if (n_sets == 2 && !ctx->stream2) {
                 int prio_lo = 0, prio_hi = 0;  // (the estimator passes' stream: highest priority, their workgroups are dispatched first)
                 (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -1586,8 +1599,38 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 hipLaunchKernelGGL(mc::bin_count_kernel, dim3(bin_blocks), dim3(256), hist_lds, es, lg.keys, lg.region_count, lg.n_regions,
                                    lg.region_capacity, n_bins, bin_count);
                 hipLaunchKernelGGL(mc::bin_scan_kernel, dim3(1), dim3(256), 0, es, bin_count, n_bins, bin_start, bin_fill, slice_start);
+                if (partition) {  // estimator_partition.hpp: by shell into the scratch copy, by bin back into the set's own buffer
+                    unsigned *shell_fill = slice_start + (n_bins + 2);
+                    mc::LineVisitRecord *scratch = ctx->log_part.as<mc::LineVisitRecord>();
+                    auto bits_of = [](int n) { int b = 0; while ((1 << b) < n) ++b; return b; };
+                    hipLaunchKernelGGL(mc::partition_shell_fill_kernel, dim3(1), dim3(256), 0, es, bin_start, lg.tiles_per_shell, ctx->n_shells, shell_fill);
+                    const int part_blocks = cus * 2;
+                    hipLaunchKernelGGL(mc::partition_kernel<true>, dim3(part_blocks), dim3(mc::PART_THREADS), 0, es, lg.records, lg.keys, lg.region_count,
+                                       lg.n_regions, lg.region_capacity, (const unsigned *)nullptr, lg.tiles_per_shell, ctx->n_lines, bits_of(ctx->n_shells),
+                                       shell_fill, scratch);
+                    hipLaunchKernelGGL(mc::partition_kernel<false>, dim3(part_blocks), dim3(mc::PART_THREADS), 0, es, scratch, (const unsigned *)nullptr,
+                                       (const unsigned *)nullptr, 0, 0u, bin_start + n_bins, lg.tiles_per_shell, ctx->n_lines, bits_of(mc::PART_LOCAL_BUCKETS),
+                                       bin_fill, lg.records);
+                    if (full)
+                        hipLaunchKernelGGL((mc::accumulate_blocks_kernel<true, true>), dim3(cus * 2), dim3(64 * mc::ACCB_WAVES), 0, es, lg.records,
+                                           (const unsigned *)nullptr, bin_start, slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                    else
+                        hipLaunchKernelGGL((mc::accumulate_blocks_kernel<false, true>), dim3(cus * 2), dim3(64 * mc::ACCB_WAVES), 0, es, lg.records,
+                                           (const unsigned *)nullptr, bin_start, slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                    return hipGetLastError();
+                }
                 hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, es, lg.keys, lg.region_count, lg.n_regions,
                                    lg.region_capacity, n_bins, bin_fill, sorted);
+                if (ctx->est_accumulate == 1) {  // one add per aligned block of 8 lines (accumulate_blocks_kernel)
+                    const unsigned acc_blocks = (unsigned)(cus * 2);
+                    if (full)
+                        hipLaunchKernelGGL((mc::accumulate_blocks_kernel<true, false>), dim3(acc_blocks), dim3(64 * mc::ACCB_WAVES), 0, es, lg.records, sorted, bin_start,
+                                           slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                    else
+                        hipLaunchKernelGGL((mc::accumulate_blocks_kernel<false, false>), dim3(acc_blocks), dim3(64 * mc::ACCB_WAVES), 0, es, lg.records, sorted, bin_start,
+                                           slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                    return hipGetLastError();
+                }
                 const unsigned acc_blocks = (unsigned)(cus * 3);
                 if (full)
                     hipLaunchKernelGGL(mc::accumulate_kernel<true>, dim3(acc_blocks), dim3(64 * mc::ACC_WAVES), 0, es, lg.records, sorted, bin_start,
