@@ -263,7 +263,10 @@ __global__ void __launch_bounds__(64 * ACCB_WAVES, 8) accumulate_blocks_kernel(c
     __shared__ unsigned long long starts[ACCB_WAVES][ACCB_PASSES];
     const unsigned n_slices = slice_start[n_bins];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned long long le_mask = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    // bits of a wave mask below this lane, counted without holding the lane's own mask in registers
+    auto count_below = [](unsigned long long m) {
+        return (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    };
     for (unsigned slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
         int lo = 0, hi = n_bins;
         while (hi - lo > 1) {
@@ -292,8 +295,8 @@ __global__ void __launch_bounds__(64 * ACCB_WAVES, 8) accumulate_blocks_kernel(c
             const unsigned line = a + j + (j >= h + b ? 7u * b : 0u);   // after the blocks: a + h + 8 b + (j - h - b)
             const unsigned blk_line = a + h + 8u * jh;                  // first line of block jh
             const unsigned idx = is_blk ? (unsigned)ACCB_TILE + (blk_line >> 3) : line;
-            const bool in_tile = is_blk ? blk_line + 8u <= tile_len : line < tile_len;
-            if (in_tile) {
+            const unsigned last = is_blk ? blk_line + 7u : line;        // the last line the item covers
+            if (last < tile_len) {
                 atomicAdd(&acc_jb[idx], c_jb);
                 atomicAdd(&acc_ed[idx], c_e);
             } else if (is_blk) {
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(64 * ACCB_WAVES, 8) accumulate_blocks_kernel(c
             const unsigned n_pass = (total + 63) >> 6;  // <= 45
             if (lane < ACCB_PASSES) starts[w][lane] = 0ull;
             if (m) {  // staged in compacted order: the q-th record that starts is the q-th staged one
-                const int pos = __popcll(__ballot(true) & ((1ull << lane) - 1ull));
+                const unsigned pos = count_below(__ballot(true));
                 Staged st;
                 st.c_e = rec.c_e; st.c_jb = rec.c_jb; st.ahb = a | (h << 12) | (b << 15); st.first = excl;
                 staged[w][pos] = st;
@@ -340,7 +343,8 @@ __global__ void __launch_bounds__(64 * ACCB_WAVES, 8) accumulate_blocks_kernel(c
                 const unsigned long long mk = starts[w][i];
                 const unsigned t = (i << 6) + (unsigned)lane;
                 if (t < total) {
-                    const unsigned q = rec_base + (unsigned)__popcll(mk & le_mask) - 1u;
+                    // the record of item t: the last one that starts at or before it
+                    const unsigned q = rec_base + count_below(mk) + (unsigned)((mk >> lane) & 1ull) - 1u;
                     const Staged st = staged[w][q];
                     add_item(st.ahb & 0xfffu, (st.ahb >> 12) & 7u, st.ahb >> 15, t - st.first, st.c_jb, st.c_e);
                 }
