@@ -262,7 +262,7 @@ def main():
 
         out["extra"] = {
             "uniform_levels": timely(dev, "configs[2] tables, 4-8-line levels (the headline of rounds 1-3)", synthetic.BASELINE_CONFIGS[3], P, 2, 1, "uniform", 20_000, True),
-            "config5_shape": timely(dev, "configs[4] table shape", synthetic.BASELINE_CONFIGS[5], 10_000_000, 2, 1, "heavy", 3_000, True),
+            "config5_shape": timely(dev, "configs[4] table shape", synthetic.BASELINE_CONFIGS[5], 10_000_000, 2, 2, "heavy", 3_000, True),
         }
     if pg.rank == 0:
         print(json.dumps(out), flush=True)
@@ -347,9 +347,8 @@ def extra_leg(device: int, name: str, kw: dict, P: int, steps: int, warmup: int,
     radius = float(prob.geometry.r_inner[0])
     eng.create_blackbody_packets(P, radius, T_INNER, first=0, count=P)
     t_build = time.perf_counter() - t_build
-    for _ in range(warmup):
-        eng.reset_estimators(); eng.propagate()
-    eng.synchronize()
+    for _ in range(warmup):  # (synchronised one by one: the engine sizes its line-visit log from the traces per packet the LAST finished call
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()  # measured, so a call may still re-allocate tens of GB once)
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.reset_estimators(); eng.propagate()
