@@ -235,6 +235,11 @@ static void move_across_shell_boundary(int64_t *shell, int64_t *status, int64_t 
 static int64_t *g_trace_log = NULL, g_trace_log_cap = 0, g_trace_log_n = 0;
 void oracle_set_trace_log(int64_t *buf, int64_t capacity_records) { g_trace_log = buf; g_trace_log_cap = capacity_records; g_trace_log_n = 0; }
 int64_t oracle_trace_log_count(void) { return g_trace_log_n; }
+/* analysis hook (tools/vpacket_stats.py), single-threaded runs only: one record {first shell, shell crossings traced, lines visited,
+ * crossing at which the Russian roulette dropped it or -1} per v-packet */
+static int64_t *g_vtrace_log = NULL, g_vtrace_log_cap = 0, g_vtrace_log_n = 0;
+void oracle_set_vtrace_log(int64_t *buf, int64_t capacity_records) { g_vtrace_log = buf; g_vtrace_log_cap = capacity_records; g_vtrace_log_n = 0; }
+int64_t oracle_vtrace_log_count(void) { return g_vtrace_log_n; }
 
 static int trace_packet(const run_ctx *c, rpacket *p, mt_state *rng, double chi_cont, double *out_distance,
                         int *out_type, int64_t *out_delta, counters *cn)
@@ -427,11 +432,14 @@ static int trace_vpacket(const run_ctx *c, vpacket *v, mt_state *rng, double *ta
 { /* virtual_packet.py:179-244 */
     double tau = 0.0;
     const double tau_russian = c->cfg->vpacket_tau_russian, survival = c->cfg->survival_probability;
+    const int64_t log_shell = v->current_shell_id, log_visits0 = cn->c[TARDIS_MC_CNT_VPACKET_LINE_VISITS];
+    int64_t log_crossings = 0, log_dropped = -1;
     for (;;) {
         double tau_shell, d_boundary;
         int64_t delta;
         int err = trace_vpacket_within_shell(c, v, &tau_shell, &d_boundary, &delta, cn);
         if (err) return err;
+        ++log_crossings;
         tau += tau_shell;
         move_across_shell_boundary(&v->current_shell_id, &v->status, delta, c->geo->n_shells);
         if (tau > tau_russian) {
@@ -439,6 +447,7 @@ static int trace_vpacket(const run_ctx *c, vpacket *v, mt_state *rng, double *ta
             if (ev > survival) {
                 v->energy = 0.0;
                 v->status = ST_EMITTED;
+                log_dropped = log_crossings;
             } else {
                 v->energy = v->energy / survival * m_exp(c, -tau);
                 tau = 0.0;
@@ -448,6 +457,10 @@ static int trace_vpacket(const run_ctx *c, vpacket *v, mt_state *rng, double *ta
         v->mu = (v->mu * v->r + d_boundary) / new_r;
         v->r = new_r;
         if (v->status == ST_EMITTED) break;
+    }
+    if (g_vtrace_log && g_vtrace_log_n < g_vtrace_log_cap) {
+        int64_t *r = g_vtrace_log + 4 * g_vtrace_log_n++;
+        r[0] = log_shell; r[1] = log_crossings; r[2] = cn->c[TARDIS_MC_CNT_VPACKET_LINE_VISITS] - log_visits0; r[3] = log_dropped;
     }
     *tau_out = tau;
     return 0;
