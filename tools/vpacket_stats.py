@@ -122,6 +122,47 @@ def phased(c, K, width=64):
 
 for K in (100, 250, 500, 640):
     print(f"  one phase per {K:3d} items, ends with its last item        : {phased(stream[:150_000], K):.3f}")
+
+
+def makespan(items, width=64):
+    import heapq
+    lanes = [0] * width
+    for x in items:
+        heapq.heappush(lanes, heapq.heappop(lanes) + int(x))
+    return max(lanes)
+
+
+def rounds_of_six(vols, K, asynchronous):
+    """The shipped rounds: an owner hands over at most six v-packets at a time (the rest needs the draws the first six consumed).
+    Synchronous = the wave's round ends with its longest item, then all owners hand over the rest; asynchronous = an owner hands over its
+    rest as soon as ITS six are done (what a per-owner completion counter would buy)."""
+    import heapq
+    busy = span = 0
+    for a in range(0, len(vols) - K + 1, K):
+        v = vols[a:a + K]
+        busy += int(v.sum())
+        if not asynchronous:
+            span += makespan(v[:, :6].reshape(-1)) + makespan(v[:, 6:].reshape(-1))
+            continue
+        lanes = [0] * 64
+        done_at = np.zeros(K, dtype=np.int64)
+        for o in range(K):          # first rounds, in owner order
+            for x in v[o, :6]:
+                t = heapq.heappop(lanes) + int(x)
+                heapq.heappush(lanes, t)
+                done_at[o] = max(done_at[o], t)
+        for o in np.argsort(done_at):  # second rounds, released when the owner's first round is complete
+            for x in v[o, 6:]:
+                t = max(heapq.heappop(lanes), int(done_at[o])) + int(x)
+                heapq.heappush(lanes, t)
+        span += max(lanes)
+    return busy / (64 * span)
+
+
+volw = vol[idx]
+for K in (20, 43, 64):
+    print(f"  rounds of <= 6 per owner, {K:2d} owners per pass: wave-synchronous {rounds_of_six(volw[:12_000], K, False):.3f}, "
+          f"per-owner asynchronous {rounds_of_six(volw[:12_000], K, True):.3f}")
 print("  dense (one crossing per lane and round from one queue)  : 1.000 by construction; 1 queue operation per crossing")
 print(f"""
 Reading.  (1) The work is short and skewed: three crossings per v-packet on average, a third of the v-packets end at their first
@@ -131,6 +172,7 @@ lane after every crossing: {pooled(stream[:200_000], 1):.2f}.  The pooled volley
 (0.36): their loss is the PHASE -- a wave's 64 owners hand over ~{int(round(64 * len(vol) / max(ref.counters["events"], 1))) * nv} items per pass (one volley per interaction), and the volley phase
 lasts until the longest of them has ended (the "one phase per K items" rows: a 30-crossing item pins the wave while 63 lanes idle) --
 and speculation: an item's position in its owner's random stream is predicted (1.32 traces per committed v-packet, at most six items
-per owner and round).  (3) A dense tracer fed from ALL waves (DESIGN 9-3) removes both; its price is one queue operation per crossing and
+per owner and round -- letting every owner start its second round as soon as ITS first is complete would add only ~0.05, last rows).
+(3) A dense tracer fed from ALL waves (DESIGN 9-3) removes both; its price is one queue operation per crossing and
 the hand-back of the draws a volley consumed.  Upper bound of the v-packet part's speed-up from occupancy
 alone: x{1 / 0.36:.1f} on ~95 % of a configs[4]-shape step.""")
