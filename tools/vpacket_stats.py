@@ -159,7 +159,56 @@ def rounds_of_six(vols, K, asynchronous):
     return busy / (64 * span)
 
 
+
+
+def carry_over(vols, K, cut, width=64):
+    """Rounds of <= 6 per owner as shipped, but a volley phase ends as soon as no item is waiting and at most `cut` lanes still trace:
+    those items stay with their lanes into the NEXT pass's phase, and their owners wait for them (no event, no new volley) while the other
+    owners go on.  K owner slots; every pass each free slot starts the next volley of the stream.  Time-stepped: one crossing per busy
+    lane and step; only the volley phases are counted."""
+    import collections
+    busy = steps = 0
+    lanes = np.zeros(width, dtype=np.int64)          # crossings left of the item a lane holds
+    lane_owner = -np.ones(width, dtype=np.int64)
+    left = [[] for _ in range(K)]                    # per owner slot: items of its volley not yet handed over
+    out = np.zeros(K, dtype=np.int64)                # per owner slot: items of its current round still tracing
+    nxt = 0
+    while nxt < len(vols) or any(left) or lanes.any():
+        for o in range(K):                           # the event phase: owners without an unfinished volley interact again
+            if out[o] == 0 and not left[o] and nxt < len(vols):
+                left[o] = list(vols[nxt]); nxt += 1
+        while True:                                  # the volley phase of this pass: rounds until the cut-off
+            queue = collections.deque()
+            for o in range(K):
+                if out[o] == 0 and left[o]:
+                    take, left[o] = left[o][:6], left[o][6:]
+                    out[o] = len(take)
+                    queue.extend((o, x) for x in take)
+            if not queue and not lanes.any():
+                break
+            while True:
+                for k in np.flatnonzero(lanes == 0):
+                    if not queue:
+                        break
+                    o, x = queue.popleft()
+                    lanes[k] = x; lane_owner[k] = o
+                n_busy = int((lanes > 0).sum())
+                more = nxt < len(vols) and any(out[o] == 0 and not left[o] for o in range(K))   # an owner that can go on exists
+                if n_busy == 0 or (not queue and n_busy <= cut and more):
+                    break
+                busy += n_busy; steps += 1
+                lanes[lanes > 0] -= 1
+                for k in np.flatnonzero((lanes == 0) & (lane_owner >= 0)):
+                    out[lane_owner[k]] -= 1; lane_owner[k] = -1
+            if not any(out[o] == 0 and left[o] for o in range(K)):
+                break                                # nobody can hand over another round now: on to the next pass
+    return busy / (width * steps)
+
+
 volw = vol[idx]
+for K in (20, 43):
+    print(f"  rounds of <= 6 + carry-over, {K:2d} owner slots: phase ends at 0 / <= 8 / <= 16 tracing lanes "
+          f"{carry_over(volw[:6_000], K, 0):.3f} / {carry_over(volw[:6_000], K, 8):.3f} / {carry_over(volw[:6_000], K, 16):.3f}")
 for K in (20, 43, 64):
     print(f"  rounds of <= 6 per owner, {K:2d} owners per pass: wave-synchronous {rounds_of_six(volw[:12_000], K, False):.3f}, "
           f"per-owner asynchronous {rounds_of_six(volw[:12_000], K, True):.3f}")
@@ -173,6 +222,9 @@ lane after every crossing: {pooled(stream[:200_000], 1):.2f}.  The pooled volley
 lasts until the longest of them has ended (the "one phase per K items" rows: a 30-crossing item pins the wave while 63 lanes idle) --
 and speculation: an item's position in its owner's random stream is predicted (1.32 traces per committed v-packet, at most six items
 per owner and round -- letting every owner start its second round as soon as ITS first is complete would add only ~0.05, last rows).
+What would pay inside the wave kernel is a CUT-OFF with carry-over, as the sweeps and the macro-atom walks already have: end the volley
+phase once nothing waits and <= 16 lanes still trace, let those lanes keep their items into the next pass's phase and their owners wait
+(the "carry-over" rows: x1.3 at <= 8 lanes, x1.5 at <= 16).
 (3) A dense tracer fed from ALL waves (DESIGN 9-3) removes both; its price is one queue operation per crossing and
 the hand-back of the draws a volley consumed.  Upper bound of the v-packet part's speed-up from occupancy
 alone: x{1 / 0.36:.1f} on ~95 % of a configs[4]-shape step.""")
