@@ -224,7 +224,7 @@ and speculation: an item's position in its owner's random stream is predicted (1
 per owner and round -- letting every owner start its second round as soon as ITS first is complete would add only ~0.05, last rows).
 What would pay inside the wave kernel is a CUT-OFF with carry-over, as the sweeps and the macro-atom walks already have: end the volley
 phase once nothing waits and <= 16 lanes still trace, let those lanes keep their items into the next pass's phase and their owners wait
-(the "carry-over" rows: x1.3 at <= 8 lanes, x1.5 at <= 16).
+(the "carry-over" rows: x1.2 - 1.3 at <= 8 lanes, x1.4 - 1.5 at <= 16).
 (3) A dense tracer fed from ALL waves (DESIGN 9-3) removes both; its price is one queue operation per crossing and
 the hand-back of the draws a volley consumed.  Upper bound of the v-packet part's speed-up from occupancy
 alone: x{1 / 0.36:.1f} on ~95 % of a configs[4]-shape step.""")
