@@ -34,8 +34,9 @@ namespace mc {
 constexpr int WV_STATE_STRIDE = 624;  // words between the MT19937 states of two packets
 constexpr int WV_RING = 8, WV_RING_VPK = 16;  // look-ahead doubles per packet (power of two; a refill adds 4, so it needs r_cnt <= 4).  16 with 8-double
                             // refills was measured: fewer refill rounds, but the extra 4 KiB of LDS costs the 12th wave of the CU
-enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3, WS_WALK = 4, WS_VOLLEY = 5 };  // WS_WALK: a macro-atom walk carried over to the next pass;
-                                                                                                              // WS_VOLLEY: a round of the packet's volley is with the v-packet tracer (volley queue)
+enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3, WS_WALK = 4, WS_VOLLEY = 5, WS_VCARRY = 6 };  // WS_WALK: a macro-atom walk carried over to the next pass;
+                                                                                                              // WS_VOLLEY: a round of the packet's volley is with the v-packet tracer (volley queue); WS_VCARRY: a round of its pooled volley was
+                                                                                                              // carried over to the next pass (VpPark)
 constexpr int RES_PENDING = -1;
 constexpr int WV_RESERVE = 32;  // packets a wave reserves per atomic on the chunk's packet counter
 
@@ -65,6 +66,14 @@ __host__ __device__ constexpr size_t wave_kernel_lds_bytes(int n_shells)
 struct __attribute__((aligned(16))) VpResult {
     double nu, energy, mu0;
     int used, visits, err, pad;
+};
+// A v-packet a worker lane was still tracing when the wave left its volley phase (cut-off with carry-over, WaveCold::vp_carry_min_active):
+// parked here over the event phase of the next pass, picked up again by the same lane in that pass's volley phase.
+struct __attribute__((aligned(16))) VpPark {
+    double r, mu, nu, energy, tau, mu0, rcp_nu, margin, v0_r, v0_energy;
+    int shell, next_line, owner, item, q, used, avail, head, v0_shell, v0_line;
+    unsigned visits;
+    int flags;  // 1: exact-division fast path, 2: screening
 };
 constexpr int VP_ROUND = 6;  // v-packets of one packet per round of a pooled volley (5 and 8 were measured: no difference)
 static_assert(2 * VP_ROUND + 3 <= 16, "a round's mu and roulette draws, plus the 4 doubles of the refill that completes them, must fit WV_RING_VPK");
@@ -140,6 +149,8 @@ struct WaveCold {
     long long chunk_first, chunk_count;
     const LaunchRec *launch;  // [chunk_count] prepared packets (launch_prep_kernel)
     VpResult *vp_scratch;  // [waves][64 * VP_ROUND]
+    VpPark *vp_park;       // [waves][64]; null: no carry-over
+    int vp_carry_min_active, vp_pad;  // pooled volleys: leave the volley phase once nothing waits and this few lanes still trace (0: never)
     // epochs (see LaneSave): where the lanes / waves of this grid are suspended; resume = this launch continues them
     LaneSave *save;      // [waves * 64]
     WaveSave *wsave;     // [waves]
@@ -705,7 +716,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     int vseq = 0;  // v-packets emitted so far by this lane's packet
     unsigned pred_bits = 0;  // roulette predictor of the volleys: bit i = v-packet i of the last volley took a roulette draw
     unsigned long long vtraced_total = 0;
-    int vq_done = 0;        // volley queue: v-packets of the running volley committed so far
+    int vq_done = 0;        // volley queue / carried round: v-packets of the running volley committed so far
+    bool v_out = false;     // carry-over: this lane's round of v-packets is handed over and not committed yet (its items live in this wave)
+    bool v_parked = false;  // carry-over: this lane holds an unfinished item in W->vp_park
     bool vq_fresh = false;  // volley queue: this lane's round was requested in THIS launch (its results come with the next one)
     int trk_count = 0, trk_boundary = 0;  // interactions_count, boundary crossings since the last interaction
     bool trk_any = false;
@@ -1446,7 +1459,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (verr || vq_done == n_v) state = WS_NEED_TRACE;  // the volley is complete: on to the next trace
                 else if (!W->vq_items) { state = WS_NEED_TRACE; cont_volley = true; }
             }
-            bool in_volley = cont_volley || (want_volley && state == WS_NEED_TRACE && !(p.nu < P.spawn_start || p.nu > P.spawn_end) && n_v > 0);
+            // carry-over: the round this lane handed over in an earlier pass is still with the wave's workers -- or, after a suspension
+            // (the workers' items are not saved), has to be handed over again
+            const bool v_carried = state == WS_VCARRY && v_out;
+            if (state == WS_VCARRY && !v_out) { state = WS_NEED_TRACE; cont_volley = true; }
+            bool in_volley = cont_volley || v_carried || (want_volley && state == WS_NEED_TRACE && !(p.nu < P.spawn_start || p.nu > P.spawn_end) && n_v > 0);
             double mu_min = 0.0, beta_inner = 0.0, mu_bin = 0.0, r_dop = 1.0;
             bool on_inner = false;
             if (in_volley) {
@@ -1510,13 +1527,44 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     }
                 }
             } else {
-            VpResult *vres = W->vp_scratch + (size_t)blockIdx.x * (64 * VP_ROUND);
+            VpResult *vres = W->vp_scratch + (size_t)blockIdx.x * (64 * VP_ROUND);  // slot: owner lane * VP_ROUND + v-packet of the round
             unsigned short *items = reinterpret_cast<unsigned short *>(sh.nu);  // [64 * VP_ROUND] over sh.nu | sh.rcp_nu (idle now)
-            int vdone = cont_volley ? vq_done : 0;  // v-packets of this lane's volley committed so far
+            int vdone = (cont_volley || v_carried) ? vq_done : 0;  // v-packets of this lane's volley committed so far
+            // Cut-off with carry-over (W->vp_carry_min_active > 0): a phase does not wait for its longest v-packets.  Once no item
+            // waits, at most that many lanes still trace and some packet of the wave could go on, the phase ends; the tracing lanes
+            // park their v-packets (VpPark) and take them up again in the next pass's phase, their owners wait in WS_VCARRY with the
+            // round uncommitted (nothing of it is committed before all of it is there: the order of the reference).
+            const int carry_cut = W->vp_park ? W->vp_carry_min_active : 0;
+            const bool others_go_on = __ballot(state != WS_DONE && !in_volley) != 0ull;  // packets that need no volley to finish first
+            // ---- worker state (lives across the rounds of a phase; across passes in W->vp_park)
+            bool tracing = false;
+            int w_owner = 0, w_item = 0, w_q = 0, w_used = 0, w_avail = 0, w_head = 0;
+            unsigned my_visits = 0;
+            VpState vs;
+            double v_rcp_nu = 0.0;
+            bool v_fast = false;
+            vs.r = vs.mu = vs.nu = vs.energy = vs.tau = vs.mu0 = 0.0; vs.shell = 0; vs.next_line = 0;
+            // screening (tau_prefix.hpp): an item predicted to be dropped by the roulette is first traced on the prefix sums; if
+            // that does not decide it, it starts again line by line from its launch state (v0_*)
+            bool screening = false;
+            double v_margin = 0.0, v0_r = 0.0, v0_energy = 0.0;
+            int v0_shell = 0, v0_line = 0;
+            if (v_parked) {
+                const VpPark k = gload(W->vp_park + ((size_t)blockIdx.x * 64 + lane));
+                vs.r = k.r; vs.mu = k.mu; vs.nu = k.nu; vs.energy = k.energy; vs.tau = k.tau; vs.mu0 = k.mu0; vs.shell = k.shell; vs.next_line = k.next_line;
+                v_rcp_nu = k.rcp_nu; v_margin = k.margin; v0_r = k.v0_r; v0_energy = k.v0_energy; v0_shell = k.v0_shell; v0_line = k.v0_line;
+                w_owner = k.owner; w_item = k.item; w_q = k.q; w_used = k.used; w_avail = k.avail; w_head = k.head;
+                my_visits = k.visits; v_fast = (k.flags & 1) != 0; screening = (k.flags & 2) != 0;
+                tracing = true;
+                v_parked = false;
+            }
+            int phase_steps = 0;
+            bool cut = false;  // the worker loop was left with lanes still tracing
             while (__ballot(in_volley)) {
-                const int n_round = in_volley ? min(VP_ROUND, n_v - vdone) : 0;
+                const bool publish = in_volley && !v_out;
+                const int n_round = publish ? min(VP_ROUND, n_v - vdone) : 0;
                 for (;;) {  // one mu draw and one roulette draw per v-packet of the round must be in the ring
-                    const unsigned long long need = __ballot(in_volley && r_cnt < 2 * n_round);
+                    const unsigned long long need = __ballot(publish && r_cnt < 2 * n_round);
                     if (!need) break;
                     refill(need, seeded_states);
                 }
@@ -1530,28 +1578,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 const int item0 = incl - n_round;
                 const int n_items = __shfl(incl, 63);
                 for (int sl = 0; sl < n_round; ++sl) items[item0 + sl] = (unsigned short)((lane << 8) | sl);
+                if (publish) v_out = true;
                 // ---- workers
                 int next = 0;
-                bool tracing = false;
-                int w_owner = 0, w_item = 0, w_q = 0, w_used = 0, w_avail = 0, w_head = 0;
-                unsigned my_visits = 0;
-                VpState vs;
-                double v_rcp_nu = 0.0;
-                bool v_fast = false;
-                vs.r = vs.mu = vs.nu = vs.energy = vs.tau = vs.mu0 = 0.0; vs.shell = 0; vs.next_line = 0;
-                // screening (tau_prefix.hpp): an item predicted to be dropped by the roulette is first traced on the prefix sums; if
-                // that does not decide it, it starts again line by line from its launch state (v0_*)
-                bool screening = false;
-                double v_margin = 0.0, v0_r = 0.0, v0_energy = 0.0;
-                int v0_shell = 0, v0_line = 0;
+                cut = false;
                 for (;;) {
                     const unsigned long long free_l = __ballot(!tracing);
+                    if (carry_cut > 0 && next >= n_items && others_go_on && phase_steps >= 4) {
+                        const int busy = 64 - __popcll(free_l);
+                        if (busy > 0 && busy <= carry_cut) { cut = true; break; }
+                    }
                     const int n_take = min(__popcll(free_l), n_items - next);
                     const int rank = __popcll(free_l & ((1ull << lane) - 1ull));
                     const bool take = !tracing && rank < n_take;
                     const int my_item = next + rank;
                     next += n_take;
                     if (!__ballot(tracing || take)) break;
+                    ++phase_steps;
                     if (n_take > 0) {  // wave-uniform: some lane starts an item and needs its owner's state
                         const int it = take ? (int)items[my_item] : 0;
                         const int o = take ? (it >> 8) : lane;
@@ -1566,7 +1609,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             const unsigned before = (f_pred >> f_vdone) & ((1u << slot) - 1u);  // predicted roulette draws of slots < slot
                             const int q = slot + __popc(before);
                             const double xi = ring[((f_head + q) & (RING - 1)) * 64 + o];
-                            w_owner = o; w_item = my_item; w_q = q + 1; w_used = 0; w_avail = f_cnt; w_head = f_head;
+                            w_owner = o; w_item = o * VP_ROUND + slot; w_q = q + 1; w_used = 0; w_avail = f_cnt; w_head = f_head;
                             double v_mu = f_mu_min + (double)i * f_mu_bin + xi * f_mu_bin;
                             double weight;
                             if (f_inner) {
@@ -1615,13 +1658,35 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         }
                     }
                 }
-                // ---- the owners validate and commit their items in order
+                // ---- the owners whose round is complete validate and commit their items in order
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (in_volley) {
-                    commit_round(vres + item0, n_round, vdone);
+                int pending = 0;  // items of this lane's round that a worker still traces
+                for (unsigned long long m = __ballot(tracing); m; m &= m - 1) {
+                    const int q = __builtin_ctzll(m);
+                    if (__builtin_amdgcn_readlane(w_owner, q) == lane) ++pending;
+                }
+                if (in_volley && v_out && pending == 0) {
+                    commit_round(vres + lane * VP_ROUND, min(VP_ROUND, n_v - vdone), vdone);
+                    v_out = false;
+                    if (state == WS_VCARRY) state = WS_NEED_TRACE;  // (a carried round: the packet goes on once its volley is complete)
                     if (verr || vdone == n_v) in_volley = false;
                 }
+                // (left by the cut-off: on to the next pass unless an owner can hand over another round right away)
+                if (cut && !__ballot(in_volley && !v_out)) break;
+            }
+            if (in_volley && v_out) {  // this lane's round stays with the workers: the packet waits for it
+                state = WS_VCARRY;
+                vq_done = vdone;
+            }
+            if (tracing) {
+                VpPark k;
+                k.r = vs.r; k.mu = vs.mu; k.nu = vs.nu; k.energy = vs.energy; k.tau = vs.tau; k.mu0 = vs.mu0; k.shell = vs.shell; k.next_line = vs.next_line;
+                k.rcp_nu = v_rcp_nu; k.margin = v_margin; k.v0_r = v0_r; k.v0_energy = v0_energy; k.v0_shell = v0_shell; k.v0_line = v0_line;
+                k.owner = w_owner; k.item = w_item; k.q = w_q; k.used = w_used; k.avail = w_avail; k.head = w_head;
+                k.visits = my_visits; k.flags = (v_fast ? 1 : 0) | (screening ? 2 : 0);
+                gstore(W->vp_park + ((size_t)blockIdx.x * 64 + lane), k);
+                v_parked = true;
             }
             }
             if (verr) {  // the reference raises: the packet ends with the error code

@@ -164,6 +164,8 @@ struct TardisMcContext {
     hipEvent_t ev_join = nullptr;
     DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], wave_cold_dev;
     DevBuf seed_chk[2], vp_scratch[2];  // (vp_scratch: per buffer set -- chunks on the two streams overlap)
+    DevBuf vp_park;                     // pooled volleys with carry-over: one parked v-packet per lane
+    int vp_carry_min_active = 0;        // pooled volleys: leave the volley phase once nothing waits and this few lanes still trace (0: never; UNVERIFIED on hardware)
     // wave kernel: word 397 of every packet's init_genrand sequence (lazy MT19937 seeding)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
     double traces_per_packet = 0.0;  // measured by the last propagate (sizes the line-visit log of the next one)
@@ -653,7 +655,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     }
     ctx->log_part.release();
     ctx->wave_cold_dev.release();
-    ctx->seed_chk[0].release(); ctx->seed_chk[1].release(); ctx->vp_scratch[0].release(); ctx->vp_scratch[1].release();
+    ctx->seed_chk[0].release(); ctx->seed_chk[1].release(); ctx->vp_scratch[0].release(); ctx->vp_scratch[1].release(); ctx->vp_park.release();
     for (auto &b : ctx->li_f64) b.release();
     for (auto &b : ctx->li_i64) b.release();
     ctx->li_rec.release();
@@ -705,6 +707,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vq_min_active") ctx->vq_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "log_tail_split") ctx->log_tail_split = value ? 1 : 0;
     else if (n == "est_pipeline") ctx->est_pipeline = value ? 1 : 0;
+    else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "est_accumulate") ctx->est_accumulate = value ? 1 : 0;
     else if (n == "log_tail_packets") ctx->log_tail_packets = (int)std::max<long long>(0, std::min<long long>(value, 1000));
     else if (n == "log_chunk_records") ctx->log_chunk_records = value <= 0 ? 0 : std::max<long long>(256, std::min<long long>(value, 1 << 20));
@@ -1549,6 +1552,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 if ((size_t)waves * 64 >= (1u << 29)) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "too many lanes for the volley queue's item words");
             }
             if (vpk) HIP_TRY(ctx, ctx->vp_scratch[0].ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(mc::VpResult)));
+            if (vpk && ctx->vp_carry_min_active > 0) HIP_TRY(ctx, ctx->vp_park.ensure((size_t)waves * 64 * sizeof(mc::VpPark)));
             HIP_TRY(ctx, ctx->wave_cold_dev.ensure(2 * sizeof(mc::WaveCold)));
             ctx->wave_cold_host.resize(2);
             hipStream_t st = ctx->stream;
@@ -1686,6 +1690,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 wc.chunk_first = 0; wc.chunk_count = n;
                 wc.launch = ctx->seed_chk[0].as<mc::LaunchRec>();
                 wc.vp_scratch = ctx->vp_scratch[0].as<mc::VpResult>();
+                wc.vp_park = (vpk && !vq_on && ctx->vp_carry_min_active > 0) ? ctx->vp_park.as<mc::VpPark>() : nullptr;
+                wc.vp_carry_min_active = ctx->vp_carry_min_active; wc.vp_pad = 0;
                 wc.save = may_suspend ? ctx->lane_save.as<mc::LaneSave>() : nullptr;
                 wc.wsave = may_suspend ? ctx->wave_save.as<mc::WaveSave>() : nullptr;
                 wc.resume = epoch > 0 ? 1 : 0;
