@@ -730,6 +730,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     bool logged_any = false;  // wave-uniform: this launch has logged something
     unsigned long long visits = 0;
     unsigned dbg_rounds = 0;  // wave-uniform profiling counter: sweep rounds (reported through counters[7])
+    unsigned long long dbg_vsteps = 0, dbg_vbusy = 0;  // wave-uniform profiling counters of the pooled volleys: steps of the worker loop / lanes that traced in them
     unsigned dbg_walk = 0;    // wave-uniform test counter (debug_flags 16384: jumps out of blocks longer than one window; 32768: jumps decided by the fp64 sums)
     // lane sweep (LS): the trace this lane is sweeping (it may span several passes of the event loop).  What only the exact
     // evaluation of a line needs is parked in LDS: chi in sh.d_cont0, the boundary distance in sh.d_boundary (where the
@@ -1535,7 +1536,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             // park their v-packets (VpPark) and take them up again in the next pass's phase, their owners wait in WS_VCARRY with the
             // round uncommitted (nothing of it is committed before all of it is there: the order of the reference).
             const int carry_cut = W->vp_park ? W->vp_carry_min_active : 0;
-            const bool others_go_on = __ballot(state != WS_DONE && !in_volley) != 0ull;  // packets that need no volley to finish first
             // ---- worker state (lives across the rounds of a phase; across passes in W->vp_park)
             bool tracing = false;
             int w_owner = 0, w_item = 0, w_q = 0, w_used = 0, w_avail = 0, w_head = 0;
@@ -1584,9 +1584,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 cut = false;
                 for (;;) {
                     const unsigned long long free_l = __ballot(!tracing);
-                    if (carry_cut > 0 && next >= n_items && others_go_on && phase_steps >= 4) {
+                    if (carry_cut > 0 && next >= n_items && phase_steps >= 4) {
+                        // (only when somebody gains by it: a packet that needs no volley, or whose volley is complete, can go on)
                         const int busy = 64 - __popcll(free_l);
-                        if (busy > 0 && busy <= carry_cut) { cut = true; break; }
+                        if (busy > 0 && busy <= carry_cut && __ballot(state != WS_DONE && !in_volley) != 0ull) { cut = true; break; }
                     }
                     const int n_take = min(__popcll(free_l), n_items - next);
                     const int rank = __popcll(free_l & ((1ull << lane) - 1ull));
@@ -1595,6 +1596,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     next += n_take;
                     if (!__ballot(tracing || take)) break;
                     ++phase_steps;
+                    if (H.debug_flags & (134217728 | 268435456)) { ++dbg_vsteps; dbg_vbusy += (unsigned long long)__popcll(__ballot(tracing || take)); }
                     if (n_take > 0) {  // wave-uniform: some lane starts an item and needs its owner's state
                         const int it = take ? (int)items[my_item] : 0;
                         const int o = take ? (it >> 8) : lane;
@@ -1885,7 +1887,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         }
     // counters: wave-reduce, one atomic each
     unsigned long long v = (LS || j == 0) ? visits : 0ull;  // group sweeps: group-uniform, count once per group
-    unsigned long long e = events, m = macro, d = draws, vv = vvisits_total, vc = vcount, vt = vtraced_total;
+    unsigned long long e = events, m = macro, d = draws, vv = vvisits_total, vc = vcount;
+    unsigned long long vt = (H.debug_flags & (134217728 | 268435456)) ? 0ull : vtraced_total;  // (those flags report something else through counters[7])
     for (int off = 32; off > 0; off >>= 1) {
         v += __shfl_down(v, off); e += __shfl_down(e, off); m += __shfl_down(m, off); d += __shfl_down(d, off);
         vv += __shfl_down(vv, off); vc += __shfl_down(vc, off); vt += __shfl_down(vt, off);
@@ -1920,6 +1923,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             }
         }
         if (H.debug_flags & 16) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_rounds);  // profiling only
+        if (VPK && (H.debug_flags & 134217728)) gatomic_add_u64(&C->counters[7], dbg_vbusy);    // profiling only: lane-steps of the pooled volleys' workers
+        if (VPK && (H.debug_flags & 268435456)) gatomic_add_u64(&C->counters[7], dbg_vsteps);   // profiling only: steps of the pooled volleys' worker loop
         if (H.debug_flags & (16384 | 32768 | 65536 | 131072)) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_walk);  // tests only
         if (H.debug_flags & 2097152) gatomic_add_u64(&C->counters[7], dbg_drain_t0 ? wall_clock64() - dbg_drain_t0 : 0ull);
         if (H.debug_flags & 4194304) gatomic_add_u64(&C->counters[7], (unsigned long long)dbg_drain_passes);

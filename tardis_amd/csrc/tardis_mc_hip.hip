@@ -162,6 +162,11 @@ struct TardisMcContext {
     // chunk overlap the propagation of its neighbours
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_join = nullptr;
+    // CU partition (option pass_cus: CUs per XCD set aside for the estimator passes, 0 = off): the propagation launches of a call of several
+    // epochs run on a stream whose queue is masked to the other CUs, the passes of epoch k beside epoch k + 1 on a stream masked to these
+    int pass_cus = 0, pass_cus_built = 0;
+    hipStream_t stream_prop_m = nullptr, stream_pass_m = nullptr;
+    hipEvent_t ev_fork_m = nullptr, ev_join_m = nullptr;
     DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], wave_cold_dev;
     DevBuf seed_chk[2], vp_scratch[2];  // (vp_scratch: per buffer set -- chunks on the two streams overlap)
     DevBuf vp_park;                     // pooled volleys with carry-over: one parked v-packet per lane
@@ -672,6 +677,10 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     if (ctx->events_host) (void)hipHostFree(ctx->events_host);
     if (ctx->ev_events) (void)hipEventDestroy(ctx->ev_events);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream_prop_m) (void)hipStreamDestroy(ctx->stream_prop_m);
+    if (ctx->stream_pass_m) (void)hipStreamDestroy(ctx->stream_pass_m);
+    if (ctx->ev_fork_m) (void)hipEventDestroy(ctx->ev_fork_m);
+    if (ctx->ev_join_m) (void)hipEventDestroy(ctx->ev_join_m);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -707,6 +716,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vq_min_active") ctx->vq_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "log_tail_split") ctx->log_tail_split = value ? 1 : 0;
     else if (n == "est_pipeline") ctx->est_pipeline = value ? 1 : 0;
+    else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "est_accumulate") ctx->est_accumulate = value ? 1 : 0;
     else if (n == "log_tail_packets") ctx->log_tail_packets = (int)std::max<long long>(0, std::min<long long>(value, 1000));
@@ -1455,7 +1465,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const long long n = ctx->n_packets;
             // (volley queue: more waves than the chip holds at once -- a wave that suspends frees its slot, and the more packets are
             // in flight the more v-packets every tracer launch has to spread over its lanes)
-            const int waves = (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, (long long)cus * wave_waves_per_cu * (vq ? ctx->vq_oversubscribe : 1)));
+            // CU partition (pass_cus): only for calls long enough to run as several epochs -- the passes of an epoch then have the next one to hide behind
+            const int n_xcd = 8;  // gfx950: 8 XCDs x 32 CUs; the bits of a queue's CU mask are interleaved over the XCDs (bit k -> XCD k % 8)
+            const bool cu_split = ctx->pass_cus > 0 && !vq && ctx->log_sets != 1 && cus == 32 * n_xcd && n >= 30000000LL;
+            const int cus_prop = cu_split ? cus - n_xcd * ctx->pass_cus : cus;
+            const int waves = (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, (long long)cus_prop * wave_waves_per_cu * (vq ? ctx->vq_oversubscribe : 1)));
             // ---- the line-visit log (estimator_log.hpp): two buffer sets, one region per wave; an epoch ends when the regions
             // are full.  Sized for the whole call when that fits log_capacity (1.2x the traces per packet measured in the last
             // call, 128 per packet before anything was measured), else log_capacity.
@@ -1535,6 +1549,21 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_hi));
                 HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
             }
+            const bool cu_masked = cu_split && n_sets == 2;
+            if (cu_masked && ctx->pass_cus_built != ctx->pass_cus) {
+                if (ctx->stream_prop_m) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_prop_m)); HIP_TRY(ctx, hipStreamDestroy(ctx->stream_prop_m)); ctx->stream_prop_m = nullptr; }
+                if (ctx->stream_pass_m) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream_pass_m)); HIP_TRY(ctx, hipStreamDestroy(ctx->stream_pass_m)); ctx->stream_pass_m = nullptr; }
+                uint32_t m_prop[8] = {0, 0, 0, 0, 0, 0, 0, 0}, m_pass[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int bit = 0; bit < cus; ++bit) {  // the first cus_prop bits = (32 - pass_cus) CUs of every XCD
+                    if (bit < cus_prop) m_prop[bit >> 5] |= 1u << (bit & 31);
+                    else m_pass[bit >> 5] |= 1u << (bit & 31);
+                }
+                HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&ctx->stream_prop_m, 8, m_prop));
+                HIP_TRY(ctx, hipExtStreamCreateWithCUMask(&ctx->stream_pass_m, 8, m_pass));
+                if (!ctx->ev_fork_m) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork_m, hipEventDisableTiming));
+                if (!ctx->ev_join_m) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join_m, hipEventDisableTiming));
+                ctx->pass_cus_built = ctx->pass_cus;
+            }
             for (int k = 0; k < 4; ++k)
                 if (!ctx->ev_post[k]) HIP_TRY(ctx, hipEventCreate(&ctx->ev_post[k]));
             // ---- per-lane MT19937 state buffers, launch records, suspended lanes
@@ -1557,6 +1586,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             ctx->wave_cold_host.resize(2);
             hipStream_t st = ctx->stream;
             HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
+            if (cu_masked) {  // everything of this call runs on the masked stream from here on; it is joined to the engine's stream at the end
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_fork_m, ctx->stream));
+                st = ctx->stream_prop_m;
+                HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_fork_m, 0));
+            }
             HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[0], st));
             if (n > 0) {
                 // lazy seeding: only word 397 of every start state is precomputed; the refills continue the init_genrand chains
@@ -1744,6 +1778,30 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                     if (vq_on && (long long)ctx->suspended_host[4] < vq_min_items) vq_on = false;
                     continue;
                 }
+                if (cu_masked) {
+                    // CU partition: the host first learns whether this was the last epoch.  If not, its passes run on the pass stream's CUs beside
+                    // the next epoch; the last epoch's passes take the propagation stream (its CUs are idle now) -- after the passes still
+                    // running on the pass stream, with which they share the scratch copy of the records
+                    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chunk[4]));
+                    float pms = 0.f;
+                    HIP_TRY(ctx, hipEventElapsedTime(&pms, ctx->ev_chunk[2], ctx->ev_chunk[3]));
+                    ctx->sum_prop_ms += pms;
+                    const bool last = *ctx->suspended_host == 0;
+                    hipStream_t ps = ctx->stream_pass_m;
+                    if (last) {
+                        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream_pass_m));
+                        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+                        ps = st;
+                    } else HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_chunk[3], 0));
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_post[2 * b], ps));
+                    HIP_TRY(ctx, estimator_passes(lg, b, ps));
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_post[2 * b + 1], ps));
+                    ctx->post_pending[b] = true;
+                    if (last) { call_complete = true; break; }
+                    records_done += (double)std::min<unsigned long long>((unsigned long long)ctx->suspended_host[6], pool_chunks) * (double)region_capacity;
+                    if (ctx->suspended_host[2] > 0) split_armed = false;
+                    continue;
+                }
                 if (es != st) HIP_TRY(ctx, hipStreamWaitEvent(es, ctx->ev_chunk[3], 0));
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_post[2 * b], es));
                 HIP_TRY(ctx, estimator_passes(lg, b, es));
@@ -1763,7 +1821,12 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             }
             if (!call_complete)  // (packets would be left suspended in lane_save, outputs and estimators silently incomplete)
                 return fail(ctx, TARDIS_MC_ERR_STATE, "propagate: %d launches did not finish the call (waves still suspended)", max_epochs);
-            if (n_sets == 2 && (ctx->post_pending[0] || ctx->post_pending[1])) {
+            if (cu_masked) {  // both masked streams join the engine's stream
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream_pass_m));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_join_m, st));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join_m, 0));
+            } else if (n_sets == 2 && (ctx->post_pending[0] || ctx->post_pending[1])) {
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             }
