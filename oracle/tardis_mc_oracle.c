@@ -629,6 +629,7 @@ int oracle_mc_run(const TardisMcPackets *pk, const TardisMcGeometry *geo, const 
     if (op->n_shells != geo->n_shells) return TARDIS_MC_ERR_INVALID_ARGUMENT;
     const int64_t P = pk->n_packets, S = op->n_shells, L = op->n_lines, G = cfg->n_spectrum_grid;
     if (n_threads < 1) n_threads = 1;
+    if (g_trace_log || g_vtrace_log) n_threads = 1; /* the analysis logs append with a plain counter: serial runs only */
     double *J = res->j_estimator, *nubar = res->nu_bar_estimator, *jb = res->j_blue_estimator, *ed = res->edotlu_estimator;
     double *hist = res->v_packets_energy_hist;
     int own_J = 0, own_nb = 0, own_jb = 0, own_ed = 0, own_h = 0;

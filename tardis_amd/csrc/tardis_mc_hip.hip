@@ -666,7 +666,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     ctx->li_rec.release();
     ctx->cum16.release(); ctx->rec16.release(); ctx->quad_info.release(); ctx->line_block_c.release();
     ctx->hot_sec.release(); ctx->hot_mass.release(); ctx->hot_flag.release(); ctx->blk_tab.release();
-    ctx->tau_pfx.release(); ctx->tau_rowsum.release();
+    ctx->tau_pfx.release(); ctx->tau_rowsum.release(); ctx->pfx_flag.release();
     ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
     ctx->vq_req.release(); ctx->vq_items.release(); ctx->vq_count.release(); ctx->vq_jsave.release();
     if (ctx->suspended_host) (void)hipHostFree(ctx->suspended_host);
@@ -909,7 +909,11 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
                     HIP_TRY(ctx, launch_hot(ctx->hot_flag.as<unsigned char>(), nullptr));
                     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                     ctx->have_hot = true;
+                } else {  // no block qualifies (uniform short blocks): S x levels x 64 B -- 0.5 GB at the configs[4] shape -- are not kept for nothing
+                    ctx->hot_sec.release();
+                    ctx->hot_flag.release();
                 }
+                ctx->hot_mass.release();  // (only the choice above read it)
             }
             {
                 std::vector<int> bt(2 * n_levels);
@@ -1505,6 +1509,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             if (cap > 0) {
                 region_capacity = ctx->log_chunk_records > 0 ? (unsigned)ctx->log_chunk_records : 4096u;
                 while (region_capacity > 256 && (unsigned long long)region_capacity * 4ull * (unsigned long long)waves > cap) region_capacity >>= 1;
+                region_capacity &= ~1u;  // even: a chunk of 24-byte records then starts on a 16-byte boundary (partition_kernel stages with 16-byte loads)
                 n_chunks = std::max<unsigned long long>(cap / region_capacity, (unsigned long long)waves);
                 if (n_chunks * region_capacity > 0xfffffff0ull) n_chunks = 0xfffffff0ull / region_capacity;
             }
