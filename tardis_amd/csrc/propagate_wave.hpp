@@ -51,6 +51,8 @@ struct WaveShared {
     int queue[64];                // lanes whose prepared trace waits for a worker group
 };
 constexpr size_t WAVE_SHARED_LS_BYTES = sizeof(WaveShared) - 3 * 64 * sizeof(int);
+static_assert(offsetof(WaveShared, queue) + sizeof(int) * 64 == sizeof(WaveShared) && offsetof(WaveShared, cursor) + 3 * 64 * sizeof(int) == sizeof(WaveShared),
+              "cursor | rowfast | queue are the last 768 bytes: the lane-sweep instantiations leave them out, the pooled volleys' item list lies over them");
 struct WaveSharedFull {  // only read by the full-relativity sweep
     double r[64], mu[64];
 };
@@ -672,6 +674,144 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
     return 0;
 }
 
+// The screening trace on the LINE-major prefix table (GroupArgs::tau_pfx_lm, [L + 1][S]), what the pooled volleys run.  Measured on the
+// BASELINE configs[4] shape (profiles/r05_vpacket_requests.txt): the volley phases are 71 % of the kernel and their time follows the
+// number of LANE-steps (crossings traced), not of wave steps -- doubling the lanes busy per step with the carry-over cut-off left it
+// nearly unchanged -- i.e. they are bound by the memory requests of a crossing, two of which (the row-major prefix sums at `start` and
+// at the stopping line: a 400-MB table) miss every cache.  Here a crossing costs three requests, one of them to HBM:
+//   * the stopping line e of crossing k is the start line of crossing k + 1 in the neighbouring shell: P[e][s] and P[e][s +- 1] lie in one
+//     row of the line-major table (one sector unless the two shells straddle a multiple of 8), read together once e is pinned;
+//   * the frequency at `start` and the prefix sum there are carried from the previous crossing (nl_start / p_start) instead of read again;
+//   * the frequency-bucket look-up of crossing k + 1 -- its geometry is arithmetic on the LDS tables -- travels with the window of crossing k.
+// Two dependent round trips per crossing as before (window of frequencies | bucket of k + 1, then the prefix row), three in an item's
+// first crossing (`primed` false: start line, prefix there, bucket).  Same values, same decisions, same margin as vp_screen_step().
+template <bool FULL, typename Draw>
+__device__ __forceinline__ int vp_screen_step_lm(const GroupArgs &P, Draw &&draw, int &draws_left, VpState &v, double &margin, double &nl_start, double &p_start,
+                                                 int &bucket_e, bool &primed, double rcp_nu, bool fast_nu,
+                                                 const double *__restrict__ geo /* LDS: r_inner | r_outer | n_e | tau row sums */, unsigned &vvisits)
+{
+    const int L = P.n_lines, S = P.n_shells;
+    const double t = P.t_exp;
+    int status = ST_IN_PROCESS;
+    const int start = v.next_line;
+    const MC_G double *__restrict__ plm = glob(P.tau_pfx_lm);
+    const MC_G double *__restrict__ nu_line_g = glob(P.nu_line);
+    const MC_G int *__restrict__ bucket_g = glob(P.bucket_first);
+    auto bucket_key = [&](double nu_thr) -> long long {
+        long long kk = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
+        return kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
+    };
+    double d_boundary;
+    int delta;
+    distance_boundary(v.r, v.mu, geo[v.shell], geo[S + v.shell], d_boundary, delta);
+    const double dop = doppler_factor<FULL>(v.r / t, v.mu);
+    const double comov_nu = v.nu * dop;
+    double chi_cont = geo[2 * S + v.shell] * P.sigma_thomson;
+    if (FULL) chi_cont *= dop;
+    const double tau_cont = chi_cont * d_boundary;
+    if (!primed) {  // the item's first crossing
+        nl_start = nu_line_g[(unsigned)min(start, L - 1)];
+        p_start = plm[(size_t)(unsigned)min(start, L) * (size_t)(unsigned)S + (unsigned)v.shell];
+        bucket_e = bucket_g[bucket_key(comov_nu - d_boundary * P.rcp_tc * v.nu)];
+        primed = true;
+    }
+    // where the v-packet is after this crossing; the bucket look-up of the next crossing is requested now
+    const int shell = v.shell;
+    int nshell = shell;
+    cross_shell(nshell, status, delta, S);
+    const bool leaves = status == ST_EMITTED;
+    const double new_r = sqrt(v.r * v.r + d_boundary * d_boundary + 2.0 * v.r * d_boundary * v.mu);
+    const double new_mu = (v.mu * v.r + d_boundary) / new_r;
+    int bucket_next = 0;
+    if (!leaves) {
+        double d_b2;
+        int delta2;
+        distance_boundary(new_r, new_mu, geo[nshell], geo[S + nshell], d_b2, delta2);
+        const double comov2 = v.nu * doppler_factor<FULL>(new_r / t, new_mu);
+        bucket_next = bucket_g[bucket_key(comov2 - d_b2 * P.rcp_tc * v.nu)];
+    }
+    auto d_line_of = [&](int k, double nl) -> double {
+        if (FULL) {
+            double d;
+            distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, k == L - 1, nl, t, d);
+            return d;
+        }
+        const double nu_diff = comov_nu - nl;
+        const double q = (fast_nu && mid_range(nu_diff)) ? exact_div<true>(nu_diff, v.nu, rcp_nu) : nu_diff / v.nu;
+        const double d = (fabs(q) < CLOSE_LINE_THRESHOLD) ? 0.0 : q * C_LIGHT * t;
+        return (k == L - 1) ? MISS_DISTANCE : d;
+    };
+    int e = start;
+    double nl_next = nl_start;
+    if (start < L) {
+        double d_line;
+        if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, start == L - 1, nl_start, t, d_line)) return ERR_MONTECARLO;
+        if (!(d_boundary <= d_line)) {
+            e = max(bucket_e, start + 1);
+            if (e > L - 1) e = L - 1;
+            const int w0 = max(e - 1, start + 1);
+            typedef double dbl2 __attribute__((ext_vector_type(2), aligned(8)));
+            const dbl2 wa = *reinterpret_cast<const MC_G dbl2 *>(nu_line_g + (unsigned)w0), wb = *reinterpret_cast<const MC_G dbl2 *>(nu_line_g + (unsigned)w0 + 2);
+            const double wn[4] = {wa.x, wa.y, wb.x, wb.y};
+            bool sw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw[i] = d_boundary <= d_line_of(min(w0 + i, L - 1), wn[i]);
+            int hit = -1;
+            if (sw[0]) { if (w0 == start + 1) hit = 0; }
+            else if (sw[1]) hit = 1;
+            else if (sw[2]) hit = 2;
+            else if (sw[3]) hit = 3;
+            if (hit >= 0 && w0 + hit <= L - 1) {
+                e = w0 + hit;
+                nl_next = wn[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i) if (hit == i) nl_next = wn[i];
+            } else {  // the bucket guess was further off: the reference's walk, forward then backward
+                e = sw[0] ? w0 : min(w0 + 3, L - 1);
+                for (;;) {
+                    d_line = d_line_of(e, nu_line_g[(unsigned)e]);
+                    if (d_boundary <= d_line || e == L - 1) break;
+                    ++e;
+                }
+                bool stops = d_boundary <= d_line;
+                while (e > start + 1) {
+                    if (!(d_boundary <= d_line_of(e - 1, nu_line_g[(unsigned)(e - 1)]))) break;
+                    --e;
+                    stops = true;
+                }
+                if (!stops) e = L;
+                nl_next = nu_line_g[(unsigned)min(e, L - 1)];
+            }
+        }
+        vvisits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
+        v.next_line = e;
+    }
+    const int n_sum = min(e, L) - min(start, L);
+    // the prefix row of the stopping line: closes this crossing (this shell's column) and opens the next (the neighbour's)
+    const MC_G double *__restrict__ row = plm + (size_t)(unsigned)min(e, L) * (size_t)(unsigned)S;
+    const double p_end = row[(unsigned)shell];
+    const double p_next = row[(unsigned)(leaves ? shell : nshell)];
+    const double seg = p_end - p_start;
+    const double tau_shell = tau_cont + seg;
+    v.tau += tau_shell;
+    margin += 2.3e-16 * (geo[3 * S + shell] + (double)(n_sum + 4) * tau_shell + 2.0 * v.tau);
+    v.shell = nshell;
+    nl_start = nl_next; p_start = p_next; bucket_e = bucket_next;
+    if (v.tau - 2.0 * margin > P.tau_russian) {  // the reference's `tau_trace_combined > tau_russian` is certainly true
+        if (draws_left <= 0) return ERR_UNSUPPORTED;
+        --draws_left;
+        const double ev = draw();
+        if (!(ev > P.survival_probability)) return 2;  // (a draw of exactly 0.0)
+        v.energy = 0.0;
+        return 1;
+    }
+    if (!(v.tau + 2.0 * margin < P.tau_russian)) return 2;  // too close to call
+    if (leaves) return 2;                                   // leaves the grid alive: its energy needs the reference's own sum
+    v.mu = new_mu;
+    v.r = new_r;
+    return 0;
+}
+
 // XWALK: with the macro-atom walks on the fp64 running sums compiled in (the cooperative group scan and the per-lane search: what the
 // wave kernel runs when the compact walk tables are not used -- debug flags 128 / 8192, cross-checks); the production instantiations
 // leave them out: ~1 100 instructions and two inlined MT19937 refills less.
@@ -729,6 +869,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
     int log_chunk = -1;     // wave-uniform: that chunk (-1: none yet / the pool is empty)
     bool logged_any = false;  // wave-uniform: this launch has logged something
     unsigned long long visits = 0;
+    // Profiling / test counters (reported through counters[7] under debug flags): only in the cross-check instantiations (XWALK), which the
+    // host launches whenever one of those flags is set.  They are wave-uniform, i.e. SGPRs the sweep loop has none to spare of: without
+    // them the headline instantiation has 53 instead of 69 spilled SGPRs, 14 instead of 25 spilled VGPRs, 204 instead of 254 lane moves.
+    constexpr bool DBG = XWALK;
     unsigned dbg_rounds = 0;  // wave-uniform profiling counter: sweep rounds (reported through counters[7])
     unsigned long long dbg_vsteps = 0, dbg_vbusy = 0;  // wave-uniform profiling counters of the pooled volleys: steps of the worker loop / lanes that traced in them
     unsigned dbg_walk = 0;    // wave-uniform test counter (debug_flags 16384: jumps out of blocks longer than one window; 32768: jumps decided by the fp64 sums)
@@ -869,7 +1013,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
 #endif
     for (;;) {
         // ============================================================ event phase (lane-per-packet)
-        ++dbg_passes;
+        if (DBG) ++dbg_passes;
         asm volatile("" ::: "memory");  // the cold arguments are (re)loaded here, once per pass
         const GroupArgs &P = W->P;
         const EstimatorLog &log = W->log;
@@ -1052,10 +1196,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 // the wave does not wait for its longest chains (a geometric tail: each jump ends a walk with the probability
                 // of an emission): once few lanes are still walking and others wait (their interaction is complete, or their
                 // sweep goes on), those few carry their walk over to the next pass
-                // (not with v-packets: the pooled volleys reuse the LDS in which a carried walk parks its interaction)
+                // (with v-packets only in the group-sweep instantiations: there the pooled volleys keep their item list in the sweep queue's
+                // LDS, idle between the sweep phases; in the lane-sweep ones it lies over the arrays in which a carried walk parks its interaction)
                 // (the cut-off is a share of the wave's LIVE lanes: in the drain of a call -- a wave with a handful of packets left --
                 // a fixed count would end the phase after every round and charge each of them a whole pass)
-                if (!VPK && round > 0 && __popcll(walking) <= walk_cut && __ballot(!in_macro && state != WS_DONE)) break;
+                if ((!VPK || !LS) && round > 0 && __popcll(walking) <= walk_cut && __ballot(!in_macro && state != WS_DONE)) break;
                 refill(__ballot(in_macro && !redo && r_cnt < 1), seeded_states);
                 unsigned x = 0;
                 if (in_macro) {
@@ -1065,7 +1210,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 const bool hot = in_macro && mb1 < 0, cold = in_macro && mb1 >= 0;
                 int q_lo = 0, q_hi = cold ? (mb1 + 7) >> 3 : 0;
                 const MC_G unsigned short *__restrict__ blk = glob(P.cum16) + ((size_t)p.shell * P.cum16_stride + (unsigned)(cold ? mb0 : 0));
-                if (H.debug_flags & 16384) dbg_walk += (unsigned)__popcll(__ballot(cold && mb1 > 8 * WALK_WINDOW_QUADS));  // tests: jumps out of long blocks
+                if (DBG && (H.debug_flags & 16384)) dbg_walk += (unsigned)__popcll(__ballot(cold && mb1 > 8 * WALK_WINDOW_QUADS));  // tests: jumps out of long blocks
                 // blocks of more than 32 transitions: first quad whose last entry is not below x (entries are monotone)
                 while (__ballot(cold && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1)) {
                     if (cold && mb1 > 8 * WALK_WINDOW_QUADS && q_hi - q_lo > WALK_WINDOW_QUADS - 1) {
@@ -1134,9 +1279,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         else nxt = 1;
                     }
                 }
-                if (H.debug_flags & 32768) dbg_walk += (unsigned)__popcll(__ballot(exact));  // tests: jumps decided by the fp64 sums
-                if (H.debug_flags & 65536) dbg_walk += (unsigned)__popcll(__ballot(hot && !redo));  // tests: jumps decided by a hot sector
-                if (H.debug_flags & 131072) dbg_walk += (unsigned)__popcll(__ballot(hot && redo));  // tests: numbers a hot sector did not decide
+                if (DBG && (H.debug_flags & 32768)) dbg_walk += (unsigned)__popcll(__ballot(exact));  // tests: jumps decided by the fp64 sums
+                if (DBG && (H.debug_flags & 65536)) dbg_walk += (unsigned)__popcll(__ballot(hot && !redo));  // tests: jumps decided by a hot sector
+                if (DBG && (H.debug_flags & 131072)) dbg_walk += (unsigned)__popcll(__ballot(hot && redo));  // tests: numbers a hot sector did not decide
                 // ---- second round trip: what the selected transition leads to
                 if (nxt == 1) {
                     const WalkRec rec = gload(P.rec16 + (unsigned)(mb0 + sel));
@@ -1400,7 +1545,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 }
             }
         }
-        if (H.debug_flags & (2097152 | 4194304 | 8388608)) {
+        if (DBG && (H.debug_flags & (2097152 | 4194304 | 8388608))) {
             const unsigned long long live = __ballot(state != WS_DONE);
             if (!dbg_drain_t0 && __popcll(live) < 64) dbg_drain_t0 = wall_clock64();
             if (dbg_drain_t0) { ++dbg_drain_passes; dbg_drain_lanes += (unsigned)__popcll(live); }
@@ -1529,7 +1674,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 }
             } else {
             VpResult *vres = W->vp_scratch + (size_t)blockIdx.x * (64 * VP_ROUND);  // slot: owner lane * VP_ROUND + v-packet of the round
-            unsigned short *items = reinterpret_cast<unsigned short *>(sh.nu);  // [64 * VP_ROUND] over sh.nu | sh.rcp_nu (idle now)
+            // [64 * VP_ROUND] work items: over sh.cursor | sh.rowfast | sh.queue (group sweeps: every prepared trace has been swept, the
+            // queue is empty) or over sh.nu | sh.rcp_nu (lane sweeps: no walk is carried there, so nothing is parked in them now)
+            unsigned short *items = LS ? reinterpret_cast<unsigned short *>(sh.nu) : reinterpret_cast<unsigned short *>(sh.cursor);
             int vdone = (cont_volley || v_carried) ? vq_done : 0;  // v-packets of this lane's volley committed so far
             // Cut-off with carry-over (W->vp_carry_min_active > 0): a phase does not wait for its longest v-packets.  Once no item
             // waits, at most that many lanes still trace and some packet of the wave could go on, the phase ends; the tracing lanes
@@ -1549,6 +1696,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             bool screening = false;
             double v_margin = 0.0, v0_r = 0.0, v0_energy = 0.0;
             int v0_shell = 0, v0_line = 0;
+            // (line-major screening, vp_screen_step_lm: what a crossing hands to the next one; `primed` false: the item's first crossing -- or
+            // the first after it was parked -- reads them)
+            double w_nl = 0.0, w_p = 0.0;
+            int w_bucket = 0;
+            bool w_primed = false;
             if (v_parked) {
                 const VpPark k = gload(W->vp_park + ((size_t)blockIdx.x * 64 + lane));
                 vs.r = k.r; vs.mu = k.mu; vs.nu = k.nu; vs.energy = k.energy; vs.tau = k.tau; vs.mu0 = k.mu0; vs.shell = k.shell; vs.next_line = k.next_line;
@@ -1596,7 +1748,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     next += n_take;
                     if (!__ballot(tracing || take)) break;
                     ++phase_steps;
-                    if (H.debug_flags & (134217728 | 268435456)) { ++dbg_vsteps; dbg_vbusy += (unsigned long long)__popcll(__ballot(tracing || take)); }
+                    if (DBG && (H.debug_flags & (134217728 | 268435456))) { ++dbg_vsteps; dbg_vbusy += (unsigned long long)__popcll(__ballot(tracing || take)); }
                     if (n_take > 0) {  // wave-uniform: some lane starts an item and needs its owner's state
                         const int it = take ? (int)items[my_item] : 0;
                         const int o = take ? (it >> 8) : lane;
@@ -1632,6 +1784,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             tracing = true;
                             screening = P.tau_pfx != nullptr && ((f_pred >> i) & 1u) != 0u;
                             v_margin = 0.0; v0_r = f_r; v0_energy = vs.energy; v0_shell = f_shell; v0_line = f_line;
+                            w_primed = false;
                         }
                     }
                     if (tracing) {
@@ -1643,7 +1796,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         int draws_left = w_avail - (w_q + w_used);
                         int st;
                         if (screening) {
-                            st = vp_screen_step<FULL>(P, wdraw, draws_left, vs, v_margin, v_rcp_nu, v_fast, lds_geo, my_visits);
+                            if (P.tau_pfx_lm) st = vp_screen_step_lm<FULL>(P, wdraw, draws_left, vs, v_margin, w_nl, w_p, w_bucket, w_primed, v_rcp_nu, v_fast, lds_geo, my_visits);
+                            else st = vp_screen_step<FULL>(P, wdraw, draws_left, vs, v_margin, v_rcp_nu, v_fast, lds_geo, my_visits);
                             if (st == 1 && (P.debug_flags & 67108864)) vtraced_total += 1ull << 40;  // tests: decided on the prefix sums -> counters[7] >> 40
                             if (st == 2) {  // not decided on the prefix sums: again, line by line
                                 vs.r = v0_r; vs.mu = vs.mu0; vs.energy = v0_energy; vs.tau = 0.0; vs.shell = v0_shell; vs.next_line = v0_line;
@@ -1758,7 +1912,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     const unsigned long long waiting = __ballot(state == WS_SWEEP && !s_active);
                     if (waiting && (__popcll(act) <= ls_cut || step >= H.ls_max_steps)) break;
                 }
-                ++dbg_rounds;
+                if (DBG) ++dbg_rounds;
                 if (s_active) {
                     const double *__restrict__ pn = H.nu_line + (unsigned)s_line;
                     const double *__restrict__ pt = H.tau_t + (s_row + (unsigned)s_line);
@@ -1832,7 +1986,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             const unsigned long long busy = __ballot(cur.owner >= 0 || nxt_owner >= 0);
             if (avail == 0 && !busy) break;
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): everything prefetched during the previous step has landed
-            ++dbg_rounds;
+            if (DBG) ++dbg_rounds;
             // ---- a group whose sweep ended continues with the trace whose first lines it prefetched
             if (cur.owner < 0 && nxt_owner >= 0) {
                 const int o = nxt_owner;

@@ -109,6 +109,9 @@ struct TardisMcContext {
     // heavy-tailed blocks -11 % whatever the thresholds (95 % of their jumps are decided by the sector); blocks of 12-24 rows with
     // uniformly drawn probabilities (six intervals cover ~50-70 %) lose 2.5 % at 600 -- a missed probe costs a round of the walk
     int walk_hot_min_mass = 800, walk_hot_min_mass_long = 400;
+    DevBuf tau_pfx_lm;                             // ... and line-major, [L + 1][S] (the wave kernel's pooled volleys; built from tau_pfx by the first call that needs it)
+    bool pfx_lm_valid = false;
+    int vp_screen_lm = 1;                          // option: the pooled volleys screen on the line-major table (0: on the row-major one, for A/B)
     DevBuf tau_pfx, tau_rowsum, pfx_flag;          // v-packet screening tables (tau_prefix.hpp), built at the first SCREENING call after set_opacity (+ their negative-depth flag)
     bool pfx_valid = false, pfx_negative = false;
     unsigned cum16_stride = 0;
@@ -170,7 +173,8 @@ struct TardisMcContext {
     DevBuf log_records[2], log_keys[2], log_cursor[2], log_bins[2], log_sorted[2], wave_cold_dev;
     DevBuf seed_chk[2], vp_scratch[2];  // (vp_scratch: per buffer set -- chunks on the two streams overlap)
     DevBuf vp_park;                     // pooled volleys with carry-over: one parked v-packet per lane
-    int vp_carry_min_active = 0;        // pooled volleys: leave the volley phase once nothing waits and this few lanes still trace (0: never; UNVERIFIED on hardware)
+    int vp_carry_min_active = 16;       // pooled volleys: leave the volley phase once nothing waits and this few lanes still trace (0: never).  16: -7 % on the
+                                        // configs[4] shape, -5 % on the tardis_example shape + 10 v-packets, flat from 16 to 32 (profiles/r05_volley_carry.txt)
     // wave kernel: word 397 of every packet's init_genrand sequence (lazy MT19937 seeding)
     double last_post_ms = 0.0;  // estimator passes (binning + accumulation) of the last propagate call
     double traces_per_packet = 0.0;  // measured by the last propagate (sizes the line-visit log of the next one)
@@ -666,7 +670,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     ctx->li_rec.release();
     ctx->cum16.release(); ctx->rec16.release(); ctx->quad_info.release(); ctx->line_block_c.release();
     ctx->hot_sec.release(); ctx->hot_mass.release(); ctx->hot_flag.release(); ctx->blk_tab.release();
-    ctx->tau_pfx.release(); ctx->tau_rowsum.release(); ctx->pfx_flag.release();
+    ctx->tau_pfx.release(); ctx->tau_rowsum.release(); ctx->pfx_flag.release(); ctx->tau_pfx_lm.release();
     ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
     ctx->vq_req.release(); ctx->vq_items.release(); ctx->vq_count.release(); ctx->vq_jsave.release();
     if (ctx->suspended_host) (void)hipHostFree(ctx->suspended_host);
@@ -717,6 +721,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "log_tail_split") ctx->log_tail_split = value ? 1 : 0;
     else if (n == "est_pipeline") ctx->est_pipeline = value ? 1 : 0;
     else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
+    else if (n == "vp_screen_lm") ctx->vp_screen_lm = value ? 1 : 0;
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "est_accumulate") ctx->est_accumulate = value ? 1 : 0;
     else if (n == "log_tail_packets") ctx->log_tail_packets = (int)std::max<long long>(0, std::min<long long>(value, 1000));
@@ -856,6 +861,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     ctx->have_hot = false;
     ctx->n_hot_blocks = 0;
     ctx->pfx_valid = false;  // (the prefix sums of the new tau table are built by the first propagate call that traces v-packets)
+    ctx->pfx_lm_valid = false;
     if (macro && E > 1 && !ctx->prob_negative) {
         // compact tables of the per-lane macro-atom walk (walk_tables.hpp): blocks at 16-byte aligned compact offsets.  The walk is
         // bound by the number of memory requests, and a block's window of running sums is fetched in 64-byte sectors: a block of
@@ -1417,6 +1423,17 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         P.bucket_kmin = ctx->bucket_kmin;
         P.tau_pfx = screen_on ? ctx->tau_pfx.as<double>() : nullptr;
         P.tau_rowsum = screen_on ? ctx->tau_rowsum.as<double>() : nullptr;
+        P.tau_pfx_lm = nullptr;
+        if (screen_on && wave_kernel && ctx->vp_screen_lm) {
+            // the pooled volleys of the wave kernel screen on the LINE-major copy (vp_screen_step_lm: one HBM request per crossing instead of two)
+            if (!ctx->pfx_lm_valid) {
+                const size_t S = (size_t)ctx->n_shells, L = (size_t)ctx->n_lines;
+                HIP_TRY(ctx, ctx->tau_pfx_lm.ensure(((L + 1) * S + 8) * sizeof(double)));
+                HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->tau_pfx.as<double>(), ctx->tau_pfx_lm.as<double>(), (long long)S, (long long)(L + 1)));
+                ctx->pfx_lm_valid = true;
+            }
+            P.tau_pfx_lm = ctx->tau_pfx_lm.as<double>();
+        }
         // macro-atom jumps of the wave kernel (macroatom chains and the single jump of downbranch alike): per-lane walk on the
         // compact tables (walk_tables.hpp); debug flag 8192 keeps the cooperative group scan of the fp64 running sums (macroatom) /
         // the fp64 search (downbranch), 128 the per-lane search in them (both for cross-checks)
@@ -1455,7 +1472,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 #define TMC_PICKW(G_) (vpk ? TMC_PICKW2(G_, true) : TMC_PICKW2(G_, false))
 #define TMC_PICKLS2(V_, X_) (trk ? mc::propagate_wave_kernel<false, true, 16, V_, true, X_> : mc::propagate_wave_kernel<false, false, 16, V_, true, X_>)
 #define TMC_PICKLS(V_) (xwalk ? TMC_PICKLS2(V_, true) : TMC_PICKLS2(V_, false))
-            const bool xwalk = (c.line_interaction_type != 0 && !compact_walk) || (ctx->debug_flags & 1048576) != 0;  // (flag 1048576: the long instantiations, for A/B)
+            // (flag 1048576: the long instantiations, for A/B; the flags that read the kernel's profiling / test counters: those are only compiled into the long ones)
+            const int dbg_counter_flags = 16 | 32 | 16384 | 32768 | 65536 | 131072 | 2097152 | 4194304 | 8388608 | 134217728 | 268435456;
+            const bool xwalk = (c.line_interaction_type != 0 && !compact_walk) || (ctx->debug_flags & (1048576 | dbg_counter_flags)) != 0;
             // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel; the lane-sweep
             // instantiations only use it in the cross-check walks: one width)
             const int GW = ctx->group_size ? ctx->group_size : (ctx->n_lines <= 100000 ? 8 : 16);
