@@ -58,7 +58,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 T_INNER = 1.0e4        # K, synthetic.make_problem's default photosphere temperature
 
 
-def algorithmic_bytes(c: dict, part: str = "step", screened: bool = False) -> float:
+VP_CROSSING_BYTES = 52.0  # a screened shell crossing (csrc/propagate_wave.hpp, vp_screen_step_lm): frequency-bucket word 4 B + four-line
+                          # window of frequencies 32 B + the stopping line's prefix sums of this and the next shell 16 B
+
+
+def algorithmic_bytes(c: dict, part: str = "step", screened: bool = False, crossings: float | None = None) -> float:
     """48 B per line visit (nu_line 8 + tau 8 + the read-modify-writes of j_blue and Edotlu, 16 each), 56 B
     per event, 8 B per macro-atom transition examined, 16 B per v-packet line visit, 56 B of per-packet I/O.
 
@@ -67,13 +71,17 @@ def algorithmic_bytes(c: dict, part: str = "step", screened: bool = False) -> fl
     dominant kernel's own share is part = "propagate": 16 B per line visit + the rest; part = "estimators": 32 B per visit.
 
     screened = True: the v-packet screening (csrc/tau_prefix.hpp) decides nearly every v-packet from two prefix reads per shell
-    crossing instead of its line visits, so the 16 B x Vv term no longer describes bytes any algorithm has to move: it is left out
-    (a LOWER bound of the traffic: the crossings themselves are not counted) and the SURVEY figure is reported beside it."""
+    crossing instead of its line visits, so the 16 B x Vv term no longer describes bytes any algorithm has to move.  It is replaced by
+    what a screened trace does move: 52 B per shell crossing traced (`crossings`, counted by the kernel under a profiling flag in one
+    extra untimed call: VP_CROSSING_BYTES) + the 16-B histogram read-modify-write per v-packet; without a crossing count the term is
+    left out (a lower bound).  The SURVEY figure is reported beside it."""
     per_visit = {"step": 48.0, "propagate": 16.0, "estimators": 32.0}[part]
     if part == "estimators":
         return per_visit * c["line_visits"]
-    return (per_visit * c["line_visits"] + 56.0 * c["events"] + walk_bytes(c) + 16.0 * c["vpacket_line_visits"] * (0.0 if screened else 1.0)
-            + 56.0 * c["packets"])
+    vp = 16.0 * c["vpacket_line_visits"]
+    if screened:
+        vp = (VP_CROSSING_BYTES * crossings + 16.0 * c["vpackets"]) if crossings else 0.0
+    return per_visit * c["line_visits"] + 56.0 * c["events"] + walk_bytes(c) + vp + 56.0 * c["packets"]
 
 
 def walk_bytes(c: dict) -> float:
@@ -235,9 +243,11 @@ def main():
         },
     }
     if pg.rank == 0:
+        screened = (kw.get("n_vpackets", 0) > 0 and kw["n_lines"] >= 2500 * kw["n_shells"]
+                    and not any(o.startswith("vpacket_screening=0") for o in args.option))
+        crossings = guarded(traced_crossings, eng) if (screened and n_gpus == 1) else None  # (untimed: after the steps)
         out["roofline"] = roofline_block(eng, counters, ktimes, last_ms, P, measured_traffic(args, P, max(ktimes["launches"], 1)),
-                                         screened=kw.get("n_vpackets", 0) > 0 and kw["n_lines"] >= 2500 * kw["n_shells"]
-                                         and not any(o.startswith("vpacket_screening=0") for o in args.option))
+                                         screened=screened, crossings=crossings if isinstance(crossings, float) else None)
         if n_gpus == 1:
             # (the legs below never take the headline line down with them: a failure is reported in their place)
             n_cpu = args.cpu_sample if args.cpu_sample is not None else default_cpu_sample(kw)
@@ -304,7 +314,7 @@ def guarded(leg, *a, **kw):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
-def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, traffic, screened: bool = False) -> dict:
+def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, traffic, screened: bool = False, crossings: float | None = None) -> dict:
     """`roofline` of one workload: the dominant kernel = the propagation kernel; its launches of one step are timed with HIP
     events on the stream they run on."""
     launches = max(ktimes["launches"], 1)
@@ -314,9 +324,9 @@ def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, tr
                 3: "propagate_wave_kernel (lane sweeps)", 4: "propagate_wave_kernel (volley queue)"}.get(variant, f"variant {variant}")
     kernel_ms = ktimes["propagate_ms"] / launches
     # the dominant kernel's own algorithmic bytes (see algorithmic_bytes) over its HIP-event duration
-    bytes_per_launch = algorithmic_bytes(counters, "propagate" if wave else "step", screened) / launches
+    bytes_per_launch = algorithmic_bytes(counters, "propagate" if wave else "step", screened, crossings) / launches
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    step_bytes = algorithmic_bytes(counters, "step", screened)
+    step_bytes = algorithmic_bytes(counters, "step", screened, crossings)
     step_achieved = step_bytes / (last_ms * 1e-3) / 1e9
     survey = None
     if screened:
@@ -336,8 +346,22 @@ def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, tr
                      "note": "all kernels of one iteration: launch preparation, propagation, line-estimator passes; estimator_passes_ms is the "
                              "ELAPSED time of the passes' stream -- their workgroups wait for CUs behind the next epoch's waves -- not their "
                              "work (~85 ms per epoch of 2e9 records, profiles/r04_estimator_partition.txt)"},
-            "per_packet": {k: counters[k] / max(P, 1) for k in ("line_visits", "events", "macro_transitions", "rng_draws",
-                                                                 "vpackets", "vpacket_line_visits")}}
+            "per_packet": dict({k: counters[k] / max(P, 1) for k in ("line_visits", "events", "macro_transitions", "rng_draws",
+                                                                      "vpackets", "vpacket_line_visits")},
+                               **({"vpacket_crossings_traced": crossings / max(P, 1)} if crossings else {}))}
+
+
+def traced_crossings(eng):
+    """Shell crossings the pooled volleys of the wave kernel traced in one call (incl. re-traced ones): one more untimed call of the
+    same work with the kernel's profiling counter on (debug flag 134217728 -> counters["reserved"]); None on other kernels."""
+    if eng.last_variant() not in (2, 3):
+        return None
+    eng.set_option("debug_flags", 134217728)
+    try:
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        return float(eng.last_counters()["reserved"])
+    finally:
+        eng.set_option("debug_flags", 0)
 
 
 def extra_leg(device: int, name: str, kw: dict, P: int, steps: int, warmup: int, level_sizes: str, cpu_sample: int, track: bool) -> dict:
@@ -364,13 +388,14 @@ def extra_leg(device: int, name: str, kw: dict, P: int, steps: int, warmup: int,
     elapsed = time.perf_counter() - t0
     last_ms, ktimes, counters = eng.last_propagate_ms(), eng.last_kernel_times(), eng.last_counters()
     sizes = np.diff(prob.opacity_state.macro_block_edge_index)
+    screened = kw.get("n_vpackets", 0) > 0 and kw["n_lines"] >= 2500 * kw["n_shells"]
+    crossings = traced_crossings(eng) if screened else None
     leg = {"workload": f"{name}: {P} packets/step, {kw['n_shells']} shells, {kw['n_lines']} lines, {kw['line_interaction_type']}, "
                        f"{kw.get('n_vpackets', 0)} v-packets, tracking {'on' if track else 'off'}, macro-atom blocks "
                        f"{level_sizes} (rows per block: median {int(np.median(sizes))}, max {int(sizes.max())})",
            "value": P * steps / elapsed, "unit": "packets/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
            "setup_s": t_build,
-           "roofline": roofline_block(eng, counters, ktimes, last_ms, P, None,
-                                      screened=kw.get("n_vpackets", 0) > 0 and kw["n_lines"] >= 2500 * kw["n_shells"])}
+           "roofline": roofline_block(eng, counters, ktimes, last_ms, P, None, screened=screened, crossings=crossings)}
     if cpu_sample > 0:
         leg["cpu_sample"] = cpu_baseline(prob, eng, P, radius, min(cpu_sample, P), single_thread=False)
     eng.close()

@@ -148,9 +148,6 @@ struct GroupArgs {
     // v-packet screening (tau_prefix.hpp): prefix sums of tau along every shell's row, [S][L + 1], and the row totals; null when
     // the screening is off (survival probability > 0, a negative optical depth, debug flag)
     const double *tau_pfx, *tau_rowsum;
-    // the same prefix sums LINE-major, [L + 1][S] (the wave kernel's pooled volleys, vp_screen_step_lm): the stopping line of a shell
-    // crossing is the start line of the next one, so P[e][s] (closes this crossing) and P[e][s +- 1] (opens the next) share a sector
-    const double *tau_pfx_lm;
 };
 
 struct Packet {

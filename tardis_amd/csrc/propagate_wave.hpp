@@ -102,7 +102,8 @@ constexpr int VQ_RESERVE = 256;  // items a tracer wave reserves per atomic
 struct WaveHot {
     const double *nu_line, *tau_t;
     int n_lines, n_shells, disable_line_scattering, debug_flags;
-    double t_exp, tc, rcp_tc;
+    double t_exp;  // (c t and its reciprocal, only read by the prologue of a trace, come from the cold block: what is passed by value here lives in
+                   // SGPRs through the sweep loop, and every one too many is moved through a VGPR lane there: 196 -> 96 lane moves)
     const int2 *line_block;           // lane sweep: macro-atom block of a line (null unless line_interaction_type != 0), requested as soon as a line stops the trace
     int ls_min_active, ls_max_steps;  // lane sweep: leave the sweep phase once this few lanes are still sweeping / after this many steps
     int walk_min_active;              // compact macro-atom walk: carry the walks over once this few lanes are still walking (-1: never)
@@ -674,144 +675,6 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
     return 0;
 }
 
-// The screening trace on the LINE-major prefix table (GroupArgs::tau_pfx_lm, [L + 1][S]), what the pooled volleys run.  Measured on the
-// BASELINE configs[4] shape (profiles/r05_vpacket_requests.txt): the volley phases are 71 % of the kernel and their time follows the
-// number of LANE-steps (crossings traced), not of wave steps -- doubling the lanes busy per step with the carry-over cut-off left it
-// nearly unchanged -- i.e. they are bound by the memory requests of a crossing, two of which (the row-major prefix sums at `start` and
-// at the stopping line: a 400-MB table) miss every cache.  Here a crossing costs three requests, one of them to HBM:
-//   * the stopping line e of crossing k is the start line of crossing k + 1 in the neighbouring shell: P[e][s] and P[e][s +- 1] lie in one
-//     row of the line-major table (one sector unless the two shells straddle a multiple of 8), read together once e is pinned;
-//   * the frequency at `start` and the prefix sum there are carried from the previous crossing (nl_start / p_start) instead of read again;
-//   * the frequency-bucket look-up of crossing k + 1 -- its geometry is arithmetic on the LDS tables -- travels with the window of crossing k.
-// Two dependent round trips per crossing as before (window of frequencies | bucket of k + 1, then the prefix row), three in an item's
-// first crossing (`primed` false: start line, prefix there, bucket).  Same values, same decisions, same margin as vp_screen_step().
-template <bool FULL, typename Draw>
-__device__ __forceinline__ int vp_screen_step_lm(const GroupArgs &P, Draw &&draw, int &draws_left, VpState &v, double &margin, double &nl_start, double &p_start,
-                                                 int &bucket_e, bool &primed, double rcp_nu, bool fast_nu,
-                                                 const double *__restrict__ geo /* LDS: r_inner | r_outer | n_e | tau row sums */, unsigned &vvisits)
-{
-    const int L = P.n_lines, S = P.n_shells;
-    const double t = P.t_exp;
-    int status = ST_IN_PROCESS;
-    const int start = v.next_line;
-    const MC_G double *__restrict__ plm = glob(P.tau_pfx_lm);
-    const MC_G double *__restrict__ nu_line_g = glob(P.nu_line);
-    const MC_G int *__restrict__ bucket_g = glob(P.bucket_first);
-    auto bucket_key = [&](double nu_thr) -> long long {
-        long long kk = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
-        return kk < 0 ? 0 : (kk >= P.bucket_n ? P.bucket_n - 1 : kk);
-    };
-    double d_boundary;
-    int delta;
-    distance_boundary(v.r, v.mu, geo[v.shell], geo[S + v.shell], d_boundary, delta);
-    const double dop = doppler_factor<FULL>(v.r / t, v.mu);
-    const double comov_nu = v.nu * dop;
-    double chi_cont = geo[2 * S + v.shell] * P.sigma_thomson;
-    if (FULL) chi_cont *= dop;
-    const double tau_cont = chi_cont * d_boundary;
-    if (!primed) {  // the item's first crossing
-        nl_start = nu_line_g[(unsigned)min(start, L - 1)];
-        p_start = plm[(size_t)(unsigned)min(start, L) * (size_t)(unsigned)S + (unsigned)v.shell];
-        bucket_e = bucket_g[bucket_key(comov_nu - d_boundary * P.rcp_tc * v.nu)];
-        primed = true;
-    }
-    // where the v-packet is after this crossing; the bucket look-up of the next crossing is requested now
-    const int shell = v.shell;
-    int nshell = shell;
-    cross_shell(nshell, status, delta, S);
-    const bool leaves = status == ST_EMITTED;
-    const double new_r = sqrt(v.r * v.r + d_boundary * d_boundary + 2.0 * v.r * d_boundary * v.mu);
-    const double new_mu = (v.mu * v.r + d_boundary) / new_r;
-    int bucket_next = 0;
-    if (!leaves) {
-        double d_b2;
-        int delta2;
-        distance_boundary(new_r, new_mu, geo[nshell], geo[S + nshell], d_b2, delta2);
-        const double comov2 = v.nu * doppler_factor<FULL>(new_r / t, new_mu);
-        bucket_next = bucket_g[bucket_key(comov2 - d_b2 * P.rcp_tc * v.nu)];
-    }
-    auto d_line_of = [&](int k, double nl) -> double {
-        if (FULL) {
-            double d;
-            distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, k == L - 1, nl, t, d);
-            return d;
-        }
-        const double nu_diff = comov_nu - nl;
-        const double q = (fast_nu && mid_range(nu_diff)) ? exact_div<true>(nu_diff, v.nu, rcp_nu) : nu_diff / v.nu;
-        const double d = (fabs(q) < CLOSE_LINE_THRESHOLD) ? 0.0 : q * C_LIGHT * t;
-        return (k == L - 1) ? MISS_DISTANCE : d;
-    };
-    int e = start;
-    double nl_next = nl_start;
-    if (start < L) {
-        double d_line;
-        if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, start == L - 1, nl_start, t, d_line)) return ERR_MONTECARLO;
-        if (!(d_boundary <= d_line)) {
-            e = max(bucket_e, start + 1);
-            if (e > L - 1) e = L - 1;
-            const int w0 = max(e - 1, start + 1);
-            typedef double dbl2 __attribute__((ext_vector_type(2), aligned(8)));
-            const dbl2 wa = *reinterpret_cast<const MC_G dbl2 *>(nu_line_g + (unsigned)w0), wb = *reinterpret_cast<const MC_G dbl2 *>(nu_line_g + (unsigned)w0 + 2);
-            const double wn[4] = {wa.x, wa.y, wb.x, wb.y};
-            bool sw[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sw[i] = d_boundary <= d_line_of(min(w0 + i, L - 1), wn[i]);
-            int hit = -1;
-            if (sw[0]) { if (w0 == start + 1) hit = 0; }
-            else if (sw[1]) hit = 1;
-            else if (sw[2]) hit = 2;
-            else if (sw[3]) hit = 3;
-            if (hit >= 0 && w0 + hit <= L - 1) {
-                e = w0 + hit;
-                nl_next = wn[0];
-#pragma unroll
-                for (int i = 1; i < 4; ++i) if (hit == i) nl_next = wn[i];
-            } else {  // the bucket guess was further off: the reference's walk, forward then backward
-                e = sw[0] ? w0 : min(w0 + 3, L - 1);
-                for (;;) {
-                    d_line = d_line_of(e, nu_line_g[(unsigned)e]);
-                    if (d_boundary <= d_line || e == L - 1) break;
-                    ++e;
-                }
-                bool stops = d_boundary <= d_line;
-                while (e > start + 1) {
-                    if (!(d_boundary <= d_line_of(e - 1, nu_line_g[(unsigned)(e - 1)]))) break;
-                    --e;
-                    stops = true;
-                }
-                if (!stops) e = L;
-                nl_next = nu_line_g[(unsigned)min(e, L - 1)];
-            }
-        }
-        vvisits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
-        v.next_line = e;
-    }
-    const int n_sum = min(e, L) - min(start, L);
-    // the prefix row of the stopping line: closes this crossing (this shell's column) and opens the next (the neighbour's)
-    const MC_G double *__restrict__ row = plm + (size_t)(unsigned)min(e, L) * (size_t)(unsigned)S;
-    const double p_end = row[(unsigned)shell];
-    const double p_next = row[(unsigned)(leaves ? shell : nshell)];
-    const double seg = p_end - p_start;
-    const double tau_shell = tau_cont + seg;
-    v.tau += tau_shell;
-    margin += 2.3e-16 * (geo[3 * S + shell] + (double)(n_sum + 4) * tau_shell + 2.0 * v.tau);
-    v.shell = nshell;
-    nl_start = nl_next; p_start = p_next; bucket_e = bucket_next;
-    if (v.tau - 2.0 * margin > P.tau_russian) {  // the reference's `tau_trace_combined > tau_russian` is certainly true
-        if (draws_left <= 0) return ERR_UNSUPPORTED;
-        --draws_left;
-        const double ev = draw();
-        if (!(ev > P.survival_probability)) return 2;  // (a draw of exactly 0.0)
-        v.energy = 0.0;
-        return 1;
-    }
-    if (!(v.tau + 2.0 * margin < P.tau_russian)) return 2;  // too close to call
-    if (leaves) return 2;                                   // leaves the grid alive: its energy needs the reference's own sum
-    v.mu = new_mu;
-    v.r = new_r;
-    return 0;
-}
-
 // XWALK: with the macro-atom walks on the fp64 running sums compiled in (the cooperative group scan and the per-lane search: what the
 // wave kernel runs when the compact walk tables are not used -- debug flags 128 / 8192, cross-checks); the production instantiations
 // leave them out: ~1 100 instructions and two inlined MT19937 refills less.
@@ -1096,7 +959,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 if (!(info & 8)) p.next_line_id = stop_line;
                 if (code == 4) err = ERR_MONTECARLO;
                 type = code == 1 ? IT_BOUNDARY : (code == 2 ? IT_ESCATTERING : IT_LINE);
-                if (P.debug_flags & 1) n_visit = 0;
+                if (DBG && (P.debug_flags & 1)) n_visit = 0;
             }
             // every wave appends to the chunk it holds: no atomics, no empty slots
             const unsigned long long have = __ballot(n_visit > 0);
@@ -1136,7 +999,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 const double comov_nu = p.nu * dop;
                 const double comov_energy = p.energy * dop;
                 const double dist_est = FULL ? distance * dop : distance;
-                if (!(P.debug_flags & 2)) {
+                if (!(DBG && (P.debug_flags & 2))) {
                     atomicAdd(&lds_J[p.shell], comov_energy * dist_est);
                     atomicAdd(&lds_nubar[p.shell], comov_energy * dist_est * comov_nu);
                 }
@@ -1186,7 +1049,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             // A block with a hot sector (walk_tables.hpp; mb1 < 0, mb0 = block id) is entered through that sector: ONE request decides
             // the jump and names its destination when the number drawn falls into one of the block's six widest intervals; else
             // the same number is looked up in the block's own tables in the next round (`redo`).
-            const int walk_cut = (H.debug_flags & 16777216) ? H.walk_min_active : (H.walk_min_active * __popcll(__ballot(state != WS_DONE))) >> 6;
+            const int walk_cut = (DBG && (H.debug_flags & 16777216)) ? H.walk_min_active : (H.walk_min_active * __popcll(__ballot(state != WS_DONE))) >> 6;
             bool redo = false;
             double event = 0.0;
             if (resumed && mb1 >= 0 && (mb1 & WALK_REDO)) { redo = true; mb1 &= ~WALK_REDO; event = sh.tau_event[lane]; }
@@ -1696,11 +1559,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             bool screening = false;
             double v_margin = 0.0, v0_r = 0.0, v0_energy = 0.0;
             int v0_shell = 0, v0_line = 0;
-            // (line-major screening, vp_screen_step_lm: what a crossing hands to the next one; `primed` false: the item's first crossing -- or
-            // the first after it was parked -- reads them)
-            double w_nl = 0.0, w_p = 0.0;
-            int w_bucket = 0;
-            bool w_primed = false;
             if (v_parked) {
                 const VpPark k = gload(W->vp_park + ((size_t)blockIdx.x * 64 + lane));
                 vs.r = k.r; vs.mu = k.mu; vs.nu = k.nu; vs.energy = k.energy; vs.tau = k.tau; vs.mu0 = k.mu0; vs.shell = k.shell; vs.next_line = k.next_line;
@@ -1784,7 +1642,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             tracing = true;
                             screening = P.tau_pfx != nullptr && ((f_pred >> i) & 1u) != 0u;
                             v_margin = 0.0; v0_r = f_r; v0_energy = vs.energy; v0_shell = f_shell; v0_line = f_line;
-                            w_primed = false;
                         }
                     }
                     if (tracing) {
@@ -1796,8 +1653,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         int draws_left = w_avail - (w_q + w_used);
                         int st;
                         if (screening) {
-                            if (P.tau_pfx_lm) st = vp_screen_step_lm<FULL>(P, wdraw, draws_left, vs, v_margin, w_nl, w_p, w_bucket, w_primed, v_rcp_nu, v_fast, lds_geo, my_visits);
-                            else st = vp_screen_step<FULL>(P, wdraw, draws_left, vs, v_margin, v_rcp_nu, v_fast, lds_geo, my_visits);
+                            st = vp_screen_step<FULL>(P, wdraw, draws_left, vs, v_margin, v_rcp_nu, v_fast, lds_geo, my_visits);
                             if (st == 1 && (P.debug_flags & 67108864)) vtraced_total += 1ull << 40;  // tests: decided on the prefix sums -> counters[7] >> 40
                             if (st == 2) {  // not decided on the prefix sums: again, line by line
                                 vs.r = v0_r; vs.mu = vs.mu0; vs.energy = v0_energy; vs.tau = 0.0; vs.shell = v0_shell; vs.next_line = v0_line;
@@ -1861,23 +1717,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             if (go) {
                 const double velocity = p.r / t;
                 dop = doppler_factor<FULL>(velocity, p.mu);
-                double chi_e = lds_geo[2 * H.n_shells + p.shell] * P.sigma_thomson;
+                double chi_e = lds_geo[2 * P.n_shells + p.shell] * P.sigma_thomson;
                 if (FULL) chi_e *= dop;
                 double d_boundary;
                 int delta;
-                distance_boundary(p.r, p.mu, lds_geo[p.shell], lds_geo[H.n_shells + p.shell], d_boundary, delta);
+                distance_boundary(p.r, p.mu, lds_geo[p.shell], lds_geo[P.n_shells + p.shell], d_boundary, delta);
                 const double tau_event = -mcm::log(draw());
                 const double comov_nu = p.nu * dop;
                 ++events;
                 const bool fast = mid_range(p.nu) && mid_range(chi_e) && mid_range(tau_event) && mid_range(p.energy) &&
-                                  mid_range(p.r) && mid_range(comov_nu) && mid_range(P.t_exp) && !(P.debug_flags & 4);
+                                  mid_range(p.r) && mid_range(comov_nu) && mid_range(P.t_exp) && !(DBG && (P.debug_flags & 4));
                 pflags = (fast ? 1 : 0) | ((delta + 1) << 1);
                 if (LS) {
                     sh.d_cont0[lane] = chi_e; sh.d_boundary[lane] = d_boundary;
                     s_tau_event = tau_event;
                     s_tau = 0.0; s_line = p.next_line_id; s_row = (unsigned)p.shell * (unsigned)L;
-                    s_kp = ((chi_e * H.tc) / p.nu) * (1.0 + 0x1p-40);
-                    s_xb = ((d_boundary * p.nu) * H.rcp_tc) * (1.0 - 0x1p-40);
+                    s_kp = ((chi_e * P.tc) / p.nu) * (1.0 + 0x1p-40);
+                    s_xb = ((d_boundary * p.nu) * P.rcp_tc) * (1.0 - 0x1p-40);
                     s_fast = fast && mid_range(s_kp);
                     s_active = true;
                 } else {
@@ -1902,7 +1758,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
         // ============================================================ sweep phase, lane sweep: every lane its own trace
         if (LS) {
             // (like the walk's: the cut-off of the sweep phase is a share of the live lanes, see there)
-            const int ls_cut = (H.debug_flags & 16777216) ? H.ls_min_active : (H.ls_min_active * __popcll(__ballot(state != WS_DONE))) >> 6;
+            const int ls_cut = (DBG && (H.debug_flags & 16777216)) ? H.ls_min_active : (H.ls_min_active * __popcll(__ballot(state != WS_DONE))) >> 6;
             for (int step = 0;; ++step) {
                 const unsigned long long act = __ballot(s_active);
                 if (!act) break;

@@ -109,9 +109,6 @@ struct TardisMcContext {
     // heavy-tailed blocks -11 % whatever the thresholds (95 % of their jumps are decided by the sector); blocks of 12-24 rows with
     // uniformly drawn probabilities (six intervals cover ~50-70 %) lose 2.5 % at 600 -- a missed probe costs a round of the walk
     int walk_hot_min_mass = 800, walk_hot_min_mass_long = 400;
-    DevBuf tau_pfx_lm;                             // ... and line-major, [L + 1][S] (the wave kernel's pooled volleys; built from tau_pfx by the first call that needs it)
-    bool pfx_lm_valid = false;
-    int vp_screen_lm = 1;                          // option: the pooled volleys screen on the line-major table (0: on the row-major one, for A/B)
     DevBuf tau_pfx, tau_rowsum, pfx_flag;          // v-packet screening tables (tau_prefix.hpp), built at the first SCREENING call after set_opacity (+ their negative-depth flag)
     bool pfx_valid = false, pfx_negative = false;
     unsigned cum16_stride = 0;
@@ -670,7 +667,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     ctx->li_rec.release();
     ctx->cum16.release(); ctx->rec16.release(); ctx->quad_info.release(); ctx->line_block_c.release();
     ctx->hot_sec.release(); ctx->hot_mass.release(); ctx->hot_flag.release(); ctx->blk_tab.release();
-    ctx->tau_pfx.release(); ctx->tau_rowsum.release(); ctx->pfx_flag.release(); ctx->tau_pfx_lm.release();
+    ctx->tau_pfx.release(); ctx->tau_rowsum.release(); ctx->pfx_flag.release();
     ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
     ctx->vq_req.release(); ctx->vq_items.release(); ctx->vq_count.release(); ctx->vq_jsave.release();
     if (ctx->suspended_host) (void)hipHostFree(ctx->suspended_host);
@@ -721,7 +718,6 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "log_tail_split") ctx->log_tail_split = value ? 1 : 0;
     else if (n == "est_pipeline") ctx->est_pipeline = value ? 1 : 0;
     else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
-    else if (n == "vp_screen_lm") ctx->vp_screen_lm = value ? 1 : 0;
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "est_accumulate") ctx->est_accumulate = value ? 1 : 0;
     else if (n == "log_tail_packets") ctx->log_tail_packets = (int)std::max<long long>(0, std::min<long long>(value, 1000));
@@ -861,7 +857,6 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     ctx->have_hot = false;
     ctx->n_hot_blocks = 0;
     ctx->pfx_valid = false;  // (the prefix sums of the new tau table are built by the first propagate call that traces v-packets)
-    ctx->pfx_lm_valid = false;
     if (macro && E > 1 && !ctx->prob_negative) {
         // compact tables of the per-lane macro-atom walk (walk_tables.hpp): blocks at 16-byte aligned compact offsets.  The walk is
         // bound by the number of memory requests, and a block's window of running sums is fetched in 64-byte sectors: a block of
@@ -1423,17 +1418,6 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         P.bucket_kmin = ctx->bucket_kmin;
         P.tau_pfx = screen_on ? ctx->tau_pfx.as<double>() : nullptr;
         P.tau_rowsum = screen_on ? ctx->tau_rowsum.as<double>() : nullptr;
-        P.tau_pfx_lm = nullptr;
-        if (screen_on && wave_kernel && ctx->vp_screen_lm) {
-            // the pooled volleys of the wave kernel screen on the LINE-major copy (vp_screen_step_lm: one HBM request per crossing instead of two)
-            if (!ctx->pfx_lm_valid) {
-                const size_t S = (size_t)ctx->n_shells, L = (size_t)ctx->n_lines;
-                HIP_TRY(ctx, ctx->tau_pfx_lm.ensure(((L + 1) * S + 8) * sizeof(double)));
-                HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->tau_pfx.as<double>(), ctx->tau_pfx_lm.as<double>(), (long long)S, (long long)(L + 1)));
-                ctx->pfx_lm_valid = true;
-            }
-            P.tau_pfx_lm = ctx->tau_pfx_lm.as<double>();
-        }
         // macro-atom jumps of the wave kernel (macroatom chains and the single jump of downbranch alike): per-lane walk on the
         // compact tables (walk_tables.hpp); debug flag 8192 keeps the cooperative group scan of the fp64 running sums (macroatom) /
         // the fp64 search (downbranch), 128 the per-lane search in them (both for cross-checks)
@@ -1473,7 +1457,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 #define TMC_PICKLS2(V_, X_) (trk ? mc::propagate_wave_kernel<false, true, 16, V_, true, X_> : mc::propagate_wave_kernel<false, false, 16, V_, true, X_>)
 #define TMC_PICKLS(V_) (xwalk ? TMC_PICKLS2(V_, true) : TMC_PICKLS2(V_, false))
             // (flag 1048576: the long instantiations, for A/B; the flags that read the kernel's profiling / test counters: those are only compiled into the long ones)
-            const int dbg_counter_flags = 16 | 32 | 16384 | 32768 | 65536 | 131072 | 2097152 | 4194304 | 8388608 | 134217728 | 268435456;
+            const int dbg_counter_flags = 1 | 2 | 4 | 16 | 32 | 16384 | 32768 | 65536 | 131072 | 2097152 | 4194304 | 8388608 | 16777216 | 134217728 | 268435456;  // (+ the ablation flags 1 / 2 / 4 / 16777216)
             const bool xwalk = (c.line_interaction_type != 0 && !compact_walk) || (ctx->debug_flags & (1048576 | dbg_counter_flags)) != 0;
             // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel; the lane-sweep
             // instantiations only use it in the cross-check walks: one width)
@@ -1632,7 +1616,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             mc::WaveHot hot{};
             hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
             hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
-            hot.t_exp = P.t_exp; hot.tc = P.tc; hot.rcp_tc = P.rcp_tc;
+            hot.t_exp = P.t_exp;
             // cut-offs of the sweep / walk phases (lanes still busy when the wave moves on): 8 / 8 by default.  Where most blocks are
             // entered through hot sectors the event phase is shorter and later cut-offs pay: 12 / 12 measured -2.5 % on the heavy-tailed
             // configs[2] tables, +2 % on the uniform ones (profiles/r04_cutoffs.txt) -- hence only there, and never against an option

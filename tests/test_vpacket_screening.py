@@ -21,9 +21,8 @@ def _oracle(oracle, prob):
                       prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE, n_threads=oracle.max_threads(), track_last_interaction=False)
 
 
-def _run(eng, prob, variant, screening, flags=0, lm=1):
+def _run(eng, prob, variant, screening, flags=0):
     eng.set_option("variant", variant)
-    eng.set_option("vp_screen_lm", lm)  # (wave kernel: the screening on the line-major prefix table (default) or on the row-major one)
     eng.set_option("vpacket_screening", screening)
     eng.set_option("debug_flags", flags)
     eng.set_option("track_last_interaction", 0)
@@ -33,10 +32,7 @@ def _run(eng, prob, variant, screening, flags=0, lm=1):
         eng.reset_estimators(); eng.propagate(); eng.synchronize()
         return eng.get_results(track_last_interaction=False)
     finally:
-        eng.set_option("variant", -1); eng.set_option("vpacket_screening", -1); eng.set_option("debug_flags", 0); eng.set_option("vp_screen_lm", 1)
-
-
-KERNELS = [(1, 1), (2, 1), (2, 0)]  # (variant, vp_screen_lm): group kernel; wave kernel on the line-major / the row-major prefix table
+        eng.set_option("variant", -1); eng.set_option("vpacket_screening", -1); eng.set_option("debug_flags", 0)
 
 
 @pytest.fixture(scope="module")
@@ -60,19 +56,19 @@ def _same(got, ref, log):
         assert np.array_equal(got.vpacket_initial_mus[:n], ref.vpacket_initial_mus)
 
 
-@pytest.mark.parametrize("variant,lm", KERNELS)
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("name", [n for n in _golden.CASES if ("_nv2" in n or "_nv3" in n or "_nv10" in n) and "roulette" not in n])
-def test_screening_forced_on_reproduces_the_vpacket_goldens(engine, oracle, name, variant, lm):
+def test_screening_forced_on_reproduces_the_vpacket_goldens(engine, oracle, name, variant):
     prob, g = _golden.load_case(name)
     ref = _oracle(oracle, prob)
-    got = _run(engine, prob, variant, 1, lm=lm)
+    got = _run(engine, prob, variant, 1)
     _same(got, ref, "vpacket_nus" in g)
     assert_allclose(got.v_packets_energy_hist, g["v_packets_energy_hist"], rtol=EST_RTOL, atol=0)
 
 
-@pytest.mark.parametrize("variant,lm", KERNELS)
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("mode,full", [("macroatom", False), ("downbranch", True)])
-def test_screening_on_thick_ejecta_decides_most_vpackets(engine, oracle, mode, full, variant, lm):
+def test_screening_on_thick_ejecta_decides_most_vpackets(engine, oracle, mode, full, variant):
     """Optically thick lines on a fine grid: most v-packets are dropped by the roulette, a few leave the grid alive (and are traced
     line by line after the screening did not decide them); the v-packet log records every one of them."""
     prob = synthetic.make_problem(seed=41, n_packets=3000, n_shells=40, n_lines=20_000, line_interaction_type=mode, n_vpackets=4,
@@ -82,7 +78,7 @@ def test_screening_on_thick_ejecta_decides_most_vpackets(engine, oracle, mode, f
     dropped = int((ref.vpacket_energies == 0).sum())
     alive = int((ref.vpacket_energies > 0).sum())
     assert dropped > 10 * max(alive, 1) and alive > 20  # (the problem has both kinds)
-    got = _run(engine, prob, variant, 1, flags=DECIDED, lm=lm)
+    got = _run(engine, prob, variant, 1, flags=DECIDED)
     decided = got.counters["reserved"] >> 40
     _same(got, ref, True)
     assert 0.5 * dropped < decided <= 2 * dropped  # (discarded speculative traces count, too; a packet's first volley is not screened)
@@ -108,8 +104,8 @@ def test_screening_is_off_with_a_survival_probability_or_negative_optical_depths
     _same(got, ref, False)
 
 
-@pytest.mark.parametrize("variant,lm", KERNELS)
-def test_optical_depth_exactly_at_the_threshold_is_never_decided_on_prefix_sums(engine, oracle, variant, lm):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_optical_depth_exactly_at_the_threshold_is_never_decided_on_prefix_sums(engine, oracle, variant):
     """The margin of the screening, attacked (VERDICT r03 weak-1 i).  Every line of every shell has tau = 0.25 and electron
     scattering is switched off (sigma_T = 1e-200: chi d is absorbed by the sum), so a v-packet's running depth is an exact
     multiple of 0.25 in the reference's serial sum AND in the prefix sums -- and equals VPACKET_TAU_RUSSIAN = 10 exactly whenever
@@ -128,7 +124,7 @@ def test_optical_depth_exactly_at_the_threshold_is_never_decided_on_prefix_sums(
     for thr in thresholds:
         cfg.VPACKET_TAU_RUSSIAN = thr
         ref = _oracle(oracle, prob)
-        got = _run(engine, prob, variant, 1, flags=DECIDED, lm=lm)
+        got = _run(engine, prob, variant, 1, flags=DECIDED)
         # (per-packet outputs, histogram, counters: a single mis-decided tie shifts its parent's stream and shows in all of them;
         # the consolidated log -- 4e5 entries here -- is compared on the smaller problems above)
         _same(got, ref, False)
