@@ -224,6 +224,11 @@ int tardis_mc_last_counters(TardisMcContext *ctx, int64_t out_counters[TARDIS_MC
  * 1 group-per-packet, 2 wave-owner with group sweeps, 3 wave-owner with lane sweeps, 4 wave-owner with the volley queue;
  * -1 before the first call. */
 int tardis_mc_last_variant(TardisMcContext *ctx);
+/* Progress of the propagate call that is running (or of the last one): packets handed to the propagation kernel so far and the call's
+ * packet count -- what the reference's packet progress bar shows (update_packets_pbar, modes/montecarlo_transport.py:94-120,
+ * progress_bars.py).  Safe to call from ANOTHER host thread while tardis_mc_propagate blocks (it reads one device word on a stream of
+ * its own); exact for the wave-owner kernel (one packet supply per call), 0 until the call is complete for the chunked / lane kernels. */
+int tardis_mc_progress(TardisMcContext *ctx, int64_t *out_packets_started, int64_t *out_packets_total);
 /* Per-packet results of the resident packets + estimators (re-laid to [L,S]) to caller memory. */
 int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *result);
 

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -162,6 +164,14 @@ struct TardisMcContext {
     // chunk overlap the propagation of its neighbours
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_join = nullptr;
+    // tardis_mc_progress (another host thread polls while propagate blocks): the running call's packet count, whether its kernel hands
+    // packets out through next_packet over the whole call (wave kernel), whether it is complete; a stream and a pinned word of its own
+    std::atomic<long long> progress_total{0};
+    std::atomic<bool> progress_wave{false}, progress_done{true};
+    std::mutex progress_mutex;
+    hipStream_t stream_progress = nullptr;
+    hipEvent_t ev_progress_reset = nullptr;  // recorded behind the reset of next_packet at the start of a call
+    unsigned long long *progress_host = nullptr;
     // CU partition (option pass_cus: CUs per XCD set aside for the estimator passes, 0 = off): the propagation launches of a call of several
     // epochs run on a stream whose queue is masked to the other CUs, the passes of epoch k beside epoch k + 1 on a stream masked to these
     int pass_cus = 0, pass_cus_built = 0;
@@ -678,6 +688,9 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     if (ctx->events_host) (void)hipHostFree(ctx->events_host);
     if (ctx->ev_events) (void)hipEventDestroy(ctx->ev_events);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream_progress) (void)hipStreamDestroy(ctx->stream_progress);
+    if (ctx->ev_progress_reset) (void)hipEventDestroy(ctx->ev_progress_reset);
+    if (ctx->progress_host) (void)hipHostFree(ctx->progress_host);
     if (ctx->stream_prop_m) (void)hipStreamDestroy(ctx->stream_prop_m);
     if (ctx->stream_pass_m) (void)hipStreamDestroy(ctx->stream_pass_m);
     if (ctx->ev_fork_m) (void)hipEventDestroy(ctx->ev_fork_m);
@@ -1286,8 +1299,14 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // (argument blocks reach the device through store_value(): consecutive propagate calls -- iterations, chunks submitted by
     // the host -- are not serialised by a stream synchronisation here)
     HIP_TRY(ctx, store_value(ctx->stream, ctx->first_error.as<FirstErrorInit>(), FirstErrorInit{{0x7fffffffffffffffLL, 0}}));
-    HIP_TRY(ctx, ctx->next_packet.ensure(sizeof(unsigned long long)));
+    ctx->progress_done = false; ctx->progress_wave = false; ctx->progress_total = ctx->n_packets;
+    {
+        std::lock_guard<std::mutex> lock(ctx->progress_mutex);  // (tardis_mc_progress may be reading next_packet)
+        HIP_TRY(ctx, ctx->next_packet.ensure(sizeof(unsigned long long)));
+        if (!ctx->ev_progress_reset) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_progress_reset, hipEventDisableTiming));
+    }
     HIP_TRY(ctx, hipMemsetAsync(ctx->next_packet.p, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_progress_reset, ctx->stream));
     // the cooperative kernel relies on a sorted line list (bucket index, monotone stopping predicate); anything else --
     // which the reference would also mis-handle -- goes through the sequential lane-per-packet kernel
     // automatic choice: the wave-owner kernel (its pooled v-packet volleys take up to 32 v-packets per volley: one bit of
@@ -1470,6 +1489,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 #undef TMC_PICKW2
 #undef TMC_PICKW
             const long long n = ctx->n_packets;
+            ctx->progress_wave = true;  // (one packet supply for the whole call: next_packet counts the packets handed out)
             // (volley queue: more waves than the chip holds at once -- a wave that suspends frees its slot, and the more packets are
             // in flight the more v-packets every tracer launch has to spread over its lanes)
             // CU partition (pass_cus): only for calls long enough to run as several epochs -- the passes of an epoch then have the next one to hide behind
@@ -1839,6 +1859,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             }
             ctx->wave_epoch_mode = true;
+            ctx->progress_done = true;  // (every packet has been handed out and has ended: the host read "nothing suspended")
             if (ctx->track && n > 0) {  // the wave kernel's tracker records -> the boundary's arrays
                 hipLaunchKernelGGL(mc::tracker_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, F, n);
                 HIP_TRY(ctx, hipGetLastError());
@@ -1911,6 +1932,27 @@ int tardis_mc_synchronize(TardisMcContext *ctx)
     if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->progress_done = true;
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_progress(TardisMcContext *ctx, int64_t *out_packets_started, int64_t *out_packets_total)
+{
+    if (!ctx || !out_packets_started || !out_packets_total) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    const long long total = ctx->progress_total.load();
+    *out_packets_total = total;
+    *out_packets_started = 0;
+    if (ctx->progress_done.load()) { *out_packets_started = total; return TARDIS_MC_OK; }
+    if (!ctx->progress_wave.load()) return TARDIS_MC_OK;
+    std::lock_guard<std::mutex> lock(ctx->progress_mutex);
+    if (!ctx->next_packet.p || !ctx->ev_progress_reset || hipEventQuery(ctx->ev_progress_reset) != hipSuccess) return TARDIS_MC_OK;  // (not reset yet)
+    if (hipSetDevice(ctx->device) != hipSuccess) return TARDIS_MC_ERR_HIP;
+    if (!ctx->stream_progress && hipStreamCreateWithFlags(&ctx->stream_progress, hipStreamNonBlocking) != hipSuccess) return TARDIS_MC_ERR_HIP;
+    if (!ctx->progress_host && hipHostMalloc((void **)&ctx->progress_host, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return TARDIS_MC_ERR_HIP;
+    if (hipMemcpyAsync(ctx->progress_host, ctx->next_packet.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream_progress) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream_progress) != hipSuccess)
+        return TARDIS_MC_ERR_HIP;
+    *out_packets_started = (int64_t)std::min<unsigned long long>(*ctx->progress_host, (unsigned long long)std::max<long long>(total, 0));  // (a wave reserves 32 at a time)
     return TARDIS_MC_OK;
 }
 

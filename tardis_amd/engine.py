@@ -119,6 +119,13 @@ class Engine:
     def synchronize(self):
         self._check(self._L.tardis_mc_synchronize(self._h), "synchronize")
 
+    def progress(self) -> tuple[int, int]:
+        """(packets handed to the propagation kernel so far, packets of the call) of the running -- or the last -- propagate().
+        Meant to be polled from another thread while propagate() blocks (tardis_mc_progress reads one device word on its own stream)."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._L.tardis_mc_progress(self._h, C.byref(a), C.byref(b)), "progress")
+        return int(a.value), int(b.value)
+
     def last_propagate_ms(self) -> float:
         v = C.c_double()
         self._check(self._L.tardis_mc_last_propagate_ms(self._h, C.byref(v)), "last_propagate_ms")

@@ -52,6 +52,62 @@ def _fill_trackers(trackers, soa: st.LastInteractionTrackers):
             setattr(t, n, cols[n][i])
 
 
+class _PacketProgress:
+    """The reference's packet progress bar (progress_bars.update_packets_pbar, fed once per packet by the main loop,
+    modes/montecarlo_transport.py:94-120) for a call that blocks inside the library: a thread polls Engine.progress() -- packets handed
+    to the propagation kernel so far -- and moves a tqdm bar (a plain stderr line without tqdm).  `show_progress_bars=False`: nothing."""
+
+    INTERVAL = 0.2  # seconds between two polls
+
+    def __init__(self, engine, enabled: bool):
+        self.engine, self.enabled, self.interval = engine, bool(enabled), self.INTERVAL
+        self.thread = self.stop = self.bar = None
+        self.seen = 0
+
+    def _update(self, final=False):
+        try:
+            started, total = self.engine.progress()
+        except Exception:  # noqa: BLE001 -- a progress bar never takes the run down
+            return
+        if final:
+            started = total
+        if self.bar is None:
+            try:
+                from tqdm.auto import tqdm
+                self.bar = tqdm(total=total, desc="Packets", unit="pkt", leave=False)
+            except Exception:  # noqa: BLE001
+                self.bar = False
+        if self.bar:
+            self.bar.total = total
+            self.bar.update(max(started - self.seen, 0))
+        elif started != self.seen or final:
+            import sys
+            print(f"\rPackets {started}/{total}", end="\n" if final else "", file=sys.stderr, flush=True)
+        self.seen = max(self.seen, started)
+
+    def __enter__(self):
+        if self.enabled:
+            import threading
+            self.stop = threading.Event()
+
+            def poll():
+                while not self.stop.wait(self.interval):
+                    self._update()
+            self.thread = threading.Thread(target=poll, name="tardis-amd-progress", daemon=True)
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.stop.set()
+            self.thread.join()
+            if exc[0] is None:
+                self._update(final=True)
+            if self.bar:
+                self.bar.close()
+        return False
+
+
 def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, time_explosion: float,
                                        opacity_state_numba, montecarlo_configuration, spectrum_frequency_grid,
                                        trackers, number_of_vpackets: int, show_progress_bars: bool = False,
@@ -81,8 +137,9 @@ def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, 
     try:
         for _attempt in range(2):
             eng.reset_estimators()
-            eng.propagate()
-            eng.synchronize()
+            with _PacketProgress(eng, show_progress_bars):
+                eng.propagate()
+                eng.synchronize()
             res = eng.get_results(out_nus if in_place else None, out_en if in_place else None, track_last_interaction=track,
                                   vpacket_log_capacity=vlog_capacity)
             if res.vpacket_log_count <= len(res.vpacket_nus):
@@ -367,7 +424,7 @@ class MCTransportSolverHIP:
 
     def run_classic(self, transport_state, show_progress_bars=False):
         if self.resident:
-            return self._run_resident(transport_state)
+            return self._run_resident(transport_state, show_progress_bars)
         self.transport_state = transport_state
         cfg = self.montecarlo_configuration
         n = len(transport_state.packet_collection.initial_nus)
@@ -384,7 +441,7 @@ class MCTransportSolverHIP:
         transport_state.virt_logging = cfg.ENABLE_VPACKET_TRACKING
         return hist
 
-    def _run_resident(self, ts):
+    def _run_resident(self, ts, show_progress_bars=False):
         self.transport_state = ts
         cfg = self.montecarlo_configuration
         if cfg.ENABLE_VPACKET_TRACKING and cfg.NUMBER_OF_VPACKETS > 0:
@@ -405,8 +462,9 @@ class MCTransportSolverHIP:
         else:
             eng.set_packets(pc)
         eng.reset_estimators()
-        eng.propagate()
-        eng.synchronize()
+        with _PacketProgress(eng, show_progress_bars):
+            eng.propagate()
+            eng.synchronize()
         res = eng.get_results(track_last_interaction=False, want_line_estimators=False, want_packet_outputs=False)  # small arrays + error check
         if device_packets:
             pc._mark_propagated()

@@ -206,3 +206,33 @@ def test_resident_outer_iterations_with_the_device_packet_source():
     solver.run(ts2)
     with pytest.raises(RuntimeError):
         ts_old.packet_spectrum(grid)
+
+
+def test_show_progress_bars_follows_the_running_call(monkeypatch):
+    """show_progress_bars (modes/montecarlo_transport.py:94-120: the reference's packet bar advances once per packet): the wrapper
+    polls tardis_mc_progress -- packets handed to the propagation kernel so far -- from a thread while the call blocks.  The values
+    never decrease, stay within the call's packet count, end AT it, and the call's results are those of a silent call."""
+    from tardis_amd import synthetic
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=3, n_packets=3_000_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+    pc = prob.packet_collection
+    seen = []
+    real = transport._PacketProgress._update
+
+    def spy(self, final=False):
+        real(self, final)
+        seen.append((self.seen, final))
+
+    monkeypatch.setattr(transport._PacketProgress, "_update", spy)
+    with Engine(0) as eng:
+        args = (prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration, prob.spectrum_frequency_grid, None, 0)
+        transport.montecarlo_transport_with_vpackets(pc, *args, show_progress_bars=False, engine=eng)
+        assert not seen
+        quiet_nus, quiet_en = pc.output_nus.copy(), pc.output_energies.copy()
+        assert eng.progress() == (pc.number_of_packets, pc.number_of_packets)  # a finished call
+        pc.output_nus[:] = -99.0
+        monkeypatch.setattr(transport._PacketProgress, "INTERVAL", 0.001)  # (the call lasts ~15 ms)
+        transport.montecarlo_transport_with_vpackets(pc, *args, show_progress_bars=True, engine=eng)
+    values = [v for v, _ in seen]
+    assert values and values == sorted(values) and 0 <= values[0] and values[-1] == pc.number_of_packets and seen[-1][1]
+    assert np.array_equal(pc.output_nus, quiet_nus) and np.array_equal(pc.output_energies, quiet_en)

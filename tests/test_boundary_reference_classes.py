@@ -177,6 +177,13 @@ class _CheckerLibrary:
         out._obj.value = 0.0
         return 0
 
+    def tardis_mc_progress(self, h, started, total):
+        self.calls.append("progress")
+        n = self.pk["n"] if self.pk else 0
+        started._obj.value = n if self.result is not None else 0
+        total._obj.value = n
+        return 0
+
     def tardis_mc_propagate(self, h):
         self.calls.append("propagate")
         L, S, T, E = self.op["n"]
@@ -349,3 +356,27 @@ def test_integration_one_line_rebinding_inside_the_reference_solver(ref, checker
             assert np.array_equal(a.astype(np.float64), b.astype(np.float64), equal_nan=True), col
         else:
             assert np.array_equal(a, b), col
+
+
+def test_show_progress_bars_polls_the_engine_and_ends_at_the_packet_count(ref, checker_engine, monkeypatch, capsys):
+    """show_progress_bars=True (run_classic's default, modes/classic/solver.py:154-175): the wrapper polls Engine.progress() from a
+    thread while the call blocks and finishes the bar at the call's packet count; False polls nothing."""
+    eng, lib = checker_engine
+    prob, g = _golden.load_case("downbranch_nv0")
+    rpc, rgeo, rop, rcfg = _reference_objects(ref, prob)
+    seen = []
+    real = transport._PacketProgress._update
+
+    def spy(self, final=False):
+        real(self, final)
+        seen.append((self.seen, final))
+
+    monkeypatch.setattr(transport._PacketProgress, "_update", spy)
+    transport.montecarlo_transport_with_vpackets(rpc, rgeo, prob.time_explosion, rop, rcfg, prob.spectrum_frequency_grid, None, 0,
+                                                 show_progress_bars=True, packet_propagation_function=ref.packet_propagation, engine=eng)
+    assert "progress" in lib.calls and seen and seen[-1] == (rpc.number_of_packets, True)
+    assert np.array_equal(rpc.output_nus, g["output_nus"])
+    lib.calls.clear(); seen.clear()
+    transport.montecarlo_transport_with_vpackets(rpc, rgeo, prob.time_explosion, rop, rcfg, prob.spectrum_frequency_grid, None, 0,
+                                                 show_progress_bars=False, packet_propagation_function=ref.packet_propagation, engine=eng)
+    assert "progress" not in lib.calls and not seen
