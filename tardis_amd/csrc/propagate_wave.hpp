@@ -1815,6 +1815,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                     double nl[LS_CHUNK], tl[LS_CHUNK];
 #pragma unroll
                     for (int k = 0; k < LS_CHUNK; ++k) { nl[k] = pn[k]; tl[k] = pt[k]; }
+                    // (experiment, cross-check instantiations only, debug flag 524288: touch the last optical depth of the NEXT chunk with this
+                    // chunk's loads, so that the sibling sector of a 128-byte line is requested together with the first and the next step's
+                    // loads find their sectors on the way -- VERDICT r04 "next" 4; profiles/r05_tau_sibling_touch.txt)
+                    if (DBG && (H.debug_flags & 524288)) {
+                        const unsigned touch = reinterpret_cast<const unsigned *>(pt + min(2 * LS_CHUNK - 1, L - 1 + LS_CHUNK - s_line))[1];
+                        if (touch == 0x7ff00001u) ++visits;  // (never: an optical depth is not that NaN pattern; keeps the load alive)
+                    }
                     int adv = 0;  // lines of this chunk the trace has passed
                     const double comov = p.nu * dop;
                     // lines that provably do not stop the trace (see above); the first one that might is kept in f_nu / f_tau

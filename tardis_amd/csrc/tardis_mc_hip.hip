@@ -1476,7 +1476,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 #define TMC_PICKLS2(V_, X_) (trk ? mc::propagate_wave_kernel<false, true, 16, V_, true, X_> : mc::propagate_wave_kernel<false, false, 16, V_, true, X_>)
 #define TMC_PICKLS(V_) (xwalk ? TMC_PICKLS2(V_, true) : TMC_PICKLS2(V_, false))
             // (flag 1048576: the long instantiations, for A/B; the flags that read the kernel's profiling / test counters: those are only compiled into the long ones)
-            const int dbg_counter_flags = 1 | 2 | 4 | 16 | 32 | 16384 | 32768 | 65536 | 131072 | 2097152 | 4194304 | 8388608 | 16777216 | 134217728 | 268435456;  // (+ the ablation flags 1 / 2 / 4 / 16777216)
+            const int dbg_counter_flags = 1 | 2 | 4 | 16 | 32 | 16384 | 32768 | 65536 | 131072 | 2097152 | 4194304 | 8388608 | 16777216 | 134217728 | 268435456 | 524288;  // (+ the ablation flags 1 / 2 / 4 / 16777216)
             const bool xwalk = (c.line_interaction_type != 0 && !compact_walk) || (ctx->debug_flags & (1048576 | dbg_counter_flags)) != 0;
             // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel; the lane-sweep
             // instantiations only use it in the cross-check walks: one width)
