@@ -73,11 +73,9 @@ struct __attribute__((aligned(16))) VpResult {
 // parked here over the event phase of the next pass, picked up again by the same lane in that pass's volley phase.
 struct __attribute__((aligned(16))) VpPark {
     double r, mu, nu, energy, tau, mu0, rcp_nu, margin, v0_r, v0_energy;
-    double x_tau;  // VpCross: the line-by-line crossing in progress (its progress must survive: a phase may be cut every few steps)
     int shell, next_line, owner, item, q, used, avail, head, v0_shell, v0_line;
     unsigned visits;
     int flags;  // 1: exact-division fast path, 2: screening
-    int x_e, x_k;
 };
 constexpr int VP_ROUND = 6;  // v-packets of one packet per round of a pooled volley (5 and 8 were measured: no difference)
 static_assert(2 * VP_ROUND + 3 <= 16, "a round's mu and roulette draws, plus the 4 doubles of the refill that completes them, must fit WV_RING_VPK");
@@ -424,28 +422,14 @@ struct VpState {
     int shell, next_line;
 };
 
-// A line-by-line shell crossing in progress (vp_shell_step): the shell's depth so far, its stopping line (e < 0: no crossing in
-// progress) and how many of its lines have been added.
-struct VpCross {
-    double tau;
-    int e, k;
-};
-
-// trace_vpacket (:82-244), one STEP of a line-by-line shell crossing: returns 1 when the v-packet has left the grid / died, 0 to go on
-// (the crossing may or may not be complete: `x` says), < 0 error.
+// one shell crossing of trace_vpacket (:82-244): returns 1 when the v-packet has left the grid / died, 0 to go on, < 0 error.
 // Written branch-light so that the lanes of a wave (each on a different v-packet) stay converged: the stopping line is
 // pinned with a fixed number of predicate evaluations around the frequency-bucket guess (a loop only if that was not
-// enough).  The optical depths of the crossing are added in the reference's order, EIGHT PER STEP: a crossing of the configs[4]
-// shape passes ~108 lines, and while one lane of a wave added them all in one call (rounds 1-4: wave-uniform chunks with +0.0 in the
-// lanes that had fewer lines) the lanes on screened v-packets -- two round trips per crossing -- waited through ~13; line-by-line
-// traces are rare there (what the screening cannot decide, what leaves the grid alive) and still took most of the volley phases'
-// time (profiles/r05_vpacket_requests.txt).  Now the step returns after one chunk and the next call continues the sum: the
-// partial depth, the stopping line and the count live in `x`, everything else of the crossing is recomputed from the
-// unchanged v-packet.  debug flag 262144: the whole crossing in one call, as before (A/B).
-// rcp_nu = RN(1 / v.nu) serves the exact 3-instruction division (mc_device.hpp) of the resonance distances; v.nu is constant
-// along a v-packet.
+// enough), and the optical depths are added in wave-uniform chunks of 8 with exact no-op adds (+0.0) in the lanes that
+// have fewer lines.  rcp_nu = RN(1 / v.nu) serves the exact 3-instruction division (mc_device.hpp) of the resonance
+// distances; v.nu is constant along a v-packet.
 template <bool FULL, typename Draw>
-__device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, int &draws_left, VpState &v, VpCross &x, double rcp_nu, bool fast_nu,
+__device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, int &draws_left, VpState &v, double rcp_nu, bool fast_nu,
                                              const double *__restrict__ geo /* LDS: r_inner | r_outer | n_e */, unsigned &vvisits)
 {
     const int L = P.n_lines, S = P.n_shells;
@@ -453,11 +437,10 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
     int status = ST_IN_PROCESS;
     const unsigned row = (unsigned)v.shell * (unsigned)L;
     const int start = v.next_line;
-    const bool fresh = x.e < 0;
     // The step is bound by the latency of its dependent, uncoalesced loads, so everything whose address is known now is
-    // requested first: the next eight optical depths of the sum (a fresh crossing: speculatively, from `start`) and the line at `start`.
+    // requested first: the line at `start` and -- speculatively -- the first eight optical depths of the sum.
     const int start_c = min(start, L - 1);
-    const MC_G double *__restrict__ trow = glob(P.tau_t) + row + (unsigned)start_c + (unsigned)(fresh ? 0 : x.k);
+    const MC_G double *__restrict__ trow = glob(P.tau_t) + row + (unsigned)start_c;
     const MC_G double *__restrict__ nu_line_g = glob(P.nu_line);
     const double nl_start = nu_line_g[(unsigned)start_c];
     // (two optical depths per load instruction; past the end of the table there is slack, and what lies beyond the lines of the
@@ -479,101 +462,89 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
     const double comov_nu = v.nu * dop;
     double chi_cont = chi_e;
     if (FULL) chi_cont *= dop;
-    if (fresh) {
-        // the frequency bucket of the shell boundary needs nothing that is still in flight: its lookup travels with the loads
-        // above instead of forming a round trip of its own after them
-        const double nu_thr = comov_nu - d_boundary * P.rcp_tc * v.nu;
-        long long kk_b = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
-        kk_b = kk_b < 0 ? 0 : (kk_b >= P.bucket_n ? P.bucket_n - 1 : kk_b);
-        const int bucket_e = glob(P.bucket_first)[kk_b];
-        // calculate_distance_line (calculate_distances.py:66-112) of line k (frequency nl) for this v-packet
-        auto d_line_of = [&](int k, double nl) -> double {
-            if (FULL) {
-                double d;
-                distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, k == L - 1, nl, t, d);
-                return d;
-            }
-            const double nu_diff = comov_nu - nl;
-            const double q = (fast_nu && mid_range(nu_diff)) ? exact_div<true>(nu_diff, v.nu, rcp_nu) : nu_diff / v.nu;
-            const double d = (fabs(q) < CLOSE_LINE_THRESHOLD) ? 0.0 : q * C_LIGHT * t;
-            return (k == L - 1) ? MISS_DISTANCE : d;
-        };
-        int e = start;
-        if (start < L) {
-            double d_line;
-            // the reference evaluates line `start` first and raises there if it lies blueward of the packet (lines further
-            // down the sorted list can then not raise: their nu_diff is larger)
-            if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, start == L - 1, nl_start, t, d_line)) return ERR_MONTECARLO;
-            if (!(d_boundary <= d_line)) {
-                // first line after `start` whose resonance lies at or beyond the shell boundary (monotone along the list):
-                // the frequency-bucket index gives a guess, a window of four lines around it is tested in one round trip
-                e = max(bucket_e, start + 1);
-                if (e > L - 1) e = L - 1;
-                const int w0 = max(e - 1, start + 1);
-                // (two 16-byte loads: the list ends in slack, and an index clamped to the last line does not look at its frequency)
-                typedef double nu2 __attribute__((ext_vector_type(2), aligned(8)));
-                const nu2 wa = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)w0), wb = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)w0 + 2);
-                const double wn[4] = {wa.x, wa.y, wb.x, wb.y};
-                bool sw[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sw[i] = d_boundary <= d_line_of(min(w0 + i, L - 1), wn[i]);
-                bool resolved = false, stops = false;
-                if (sw[0]) {
-                    if (w0 == start + 1) { e = w0; stops = true; resolved = true; }
-                    else e = w0;  // the first stopping line lies before the window
-                } else if (sw[1]) { e = min(w0 + 1, L - 1); stops = true; resolved = true; }
-                else if (sw[2]) { e = min(w0 + 2, L - 1); stops = true; resolved = true; }
-                else if (sw[3]) { e = min(w0 + 3, L - 1); stops = true; resolved = true; }
-                else e = min(w0 + 3, L - 1);  // beyond the window
-                if (!resolved) {  // the bucket guess was further off: the reference's walk, forward then backward
-                    for (;;) {
-                        d_line = d_line_of(e, nu_line_g[(unsigned)e]);
-                        if (d_boundary <= d_line || e == L - 1) break;
-                        ++e;
-                    }
-                    stops = d_boundary <= d_line;
-                    while (e > start + 1) {
-                        if (!(d_boundary <= d_line_of(e - 1, nu_line_g[(unsigned)(e - 1)]))) break;
-                        --e;
-                        stops = true;
-                    }
-                }
-                if (!stops) e = L;  // (the reference then sums every line)
-            }
+    double tau_shell = chi_cont * d_boundary;
+    // the frequency bucket of the shell boundary needs nothing that is still in flight: its lookup travels with the loads
+    // above instead of forming a round trip of its own after them
+    const double nu_thr = comov_nu - d_boundary * P.rcp_tc * v.nu;
+    long long kk_b = (long long)((unsigned long long)__double_as_longlong(nu_thr > 0.0 ? nu_thr : 0.0) >> P.bucket_shift) - P.bucket_kmin;
+    kk_b = kk_b < 0 ? 0 : (kk_b >= P.bucket_n ? P.bucket_n - 1 : kk_b);
+    const int bucket_e = glob(P.bucket_first)[kk_b];
+    // calculate_distance_line (calculate_distances.py:66-112) of line k (frequency nl) for this v-packet
+    auto d_line_of = [&](int k, double nl) -> double {
+        if (FULL) {
+            double d;
+            distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, k == L - 1, nl, t, d);
+            return d;
         }
-        x.e = e; x.k = 0;
-        x.tau = chi_cont * d_boundary;
-    }
-    // serial-order sum of tau over [start, start + n_sum): the next eight lines, +0.0 where the crossing has none left
-    const int n_sum = (start < L) ? min(x.e, L) - start : 0;
-    {
-        const int left = n_sum - x.k;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x.tau += (k < left) ? tv[k] : 0.0;
-        x.k += 8;
-    }
-    if (P.debug_flags & 262144) {  // (A/B: the rest of the crossing here and now, wave-uniform chunks as in rounds 1-4)
-        for (; __ballot(x.k < n_sum); x.k += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-                const int o = x.k + k;
-                const tau2 z = {0.0, 0.0};
-                const tau2 w = (o < n_sum) ? *reinterpret_cast<const MC_G tau2 *>(glob(P.tau_t) + row + (unsigned)start_c + (unsigned)o) : z;
-                tv[k] = w.x; tv[k + 1] = (o + 1 < n_sum) ? w.y : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x.tau += tv[k];
-        }
-    }
-    if (x.k < n_sum) return 0;  // the crossing goes on with the next step
-    // ---- the crossing is complete
+        const double nu_diff = comov_nu - nl;
+        const double q = (fast_nu && mid_range(nu_diff)) ? exact_div<true>(nu_diff, v.nu, rcp_nu) : nu_diff / v.nu;
+        const double d = (fabs(q) < CLOSE_LINE_THRESHOLD) ? 0.0 : q * C_LIGHT * t;
+        return (k == L - 1) ? MISS_DISTANCE : d;
+    };
+    int n_sum = 0;
     if (start < L) {
-        vvisits += (unsigned)((x.e < L) ? (x.e - start + 1) : (L - start));
-        v.next_line = x.e;
+        double d_line;
+        // the reference evaluates line `start` first and raises there if it lies blueward of the packet (lines further
+        // down the sorted list can then not raise: their nu_diff is larger)
+        if (!distance_line<FULL>(v.nu, v.r, v.mu, comov_nu, start == L - 1, nl_start, t, d_line)) return ERR_MONTECARLO;
+        int e = start;
+        if (!(d_boundary <= d_line)) {
+            // first line after `start` whose resonance lies at or beyond the shell boundary (monotone along the list):
+            // the frequency-bucket index gives a guess, a window of four lines around it is tested in one round trip
+            e = max(bucket_e, start + 1);
+            if (e > L - 1) e = L - 1;
+            const int w0 = max(e - 1, start + 1);
+            // (two 16-byte loads: the list ends in slack, and an index clamped to the last line does not look at its frequency)
+            typedef double nu2 __attribute__((ext_vector_type(2), aligned(8)));
+            const nu2 wa = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)w0), wb = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)w0 + 2);
+            const double wn[4] = {wa.x, wa.y, wb.x, wb.y};
+            bool sw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw[i] = d_boundary <= d_line_of(min(w0 + i, L - 1), wn[i]);
+            bool resolved = false, stops = false;
+            if (sw[0]) {
+                if (w0 == start + 1) { e = w0; stops = true; resolved = true; }
+                else e = w0;  // the first stopping line lies before the window
+            } else if (sw[1]) { e = min(w0 + 1, L - 1); stops = true; resolved = true; }
+            else if (sw[2]) { e = min(w0 + 2, L - 1); stops = true; resolved = true; }
+            else if (sw[3]) { e = min(w0 + 3, L - 1); stops = true; resolved = true; }
+            else e = min(w0 + 3, L - 1);  // beyond the window
+            if (!resolved) {  // the bucket guess was further off: the reference's walk, forward then backward
+                for (;;) {
+                    d_line = d_line_of(e, nu_line_g[(unsigned)e]);
+                    if (d_boundary <= d_line || e == L - 1) break;
+                    ++e;
+                }
+                stops = d_boundary <= d_line;
+                while (e > start + 1) {
+                    if (!(d_boundary <= d_line_of(e - 1, nu_line_g[(unsigned)(e - 1)]))) break;
+                    --e;
+                    stops = true;
+                }
+            }
+            if (!stops) e = L;  // (the reference then sums every line)
+        }
+        n_sum = min(e, L) - start;
+        vvisits += (unsigned)((e < L) ? (e - start + 1) : (L - start));
+        v.next_line = e;
     }
-    x.e = -1;
+    // serial-order sum of tau over [start, start + n_sum): wave-uniform chunks of 8 (the first one was requested at the top),
+    // +0.0 where a lane has no line left
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tau_shell += (k < n_sum) ? tv[k] : 0.0;
+    for (int base = 8; __ballot(base < n_sum); base += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            const int o = base + k;
+            const tau2 z = {0.0, 0.0};
+            const tau2 w = (o < n_sum) ? *reinterpret_cast<const MC_G tau2 *>(trow + o) : z;
+            tv[k] = w.x; tv[k + 1] = (o + 1 < n_sum) ? w.y : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tau_shell += tv[k];
+    }
     // trace_vpacket (:179-244)
-    v.tau += x.tau;
+    v.tau += tau_shell;
     cross_shell(v.shell, status, delta, P.n_shells);
     if (v.tau > P.tau_russian) {
         if (draws_left <= 0) return ERR_UNSUPPORTED;
@@ -1432,13 +1403,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         p.shell = 0; p.status = ST_IN_PROCESS;
                         if (TRACK) { trk_count = 0; trk_boundary = 0; trk_any = false; }  // (-1 + the initial track_boundary_event)
                         state = WS_NEED_TRACE;
-                        // volley at launch (classic/packet_propagation.py:109-118).  The roulette predictor of a new packet: where the
-                        // screening is on (long line lists on fine grids: nearly every v-packet is dropped by the roulette) its first volley
-                        // is predicted dropped, too -- and therefore SCREENED.  With the predictor at zero those 1.2 % of the v-packets were
-                        // traced line by line, ~13 wave-uniform chunks of optical depths per crossing during which the wave's screened
-                        // lanes wait: a third of all steps of the worker loop, most of the volley phases' time
-                        // (profiles/r05_vpacket_requests.txt).  Scheduling only: a wrong prediction is re-traced, as ever.
-                        if (VPK) { vseq = 0; pred_bits = (P.tau_pfx && !(P.debug_flags & 2048)) ? 0xffffffffu : 0u; want_volley = true; }  // (flag 2048: the predictor of rounds 1-4, for A/B)
+                        if (VPK) { vseq = 0; pred_bits = 0; want_volley = true; }  // volley at launch (classic/packet_propagation.py:109-118)
                     }
                 }
             }
@@ -1594,15 +1559,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
             bool screening = false;
             double v_margin = 0.0, v0_r = 0.0, v0_energy = 0.0;
             int v0_shell = 0, v0_line = 0;
-            VpCross w_x;  // the line-by-line crossing in progress
-            w_x.tau = 0.0; w_x.e = -1; w_x.k = 0;
             if (v_parked) {
                 const VpPark k = gload(W->vp_park + ((size_t)blockIdx.x * 64 + lane));
                 vs.r = k.r; vs.mu = k.mu; vs.nu = k.nu; vs.energy = k.energy; vs.tau = k.tau; vs.mu0 = k.mu0; vs.shell = k.shell; vs.next_line = k.next_line;
                 v_rcp_nu = k.rcp_nu; v_margin = k.margin; v0_r = k.v0_r; v0_energy = k.v0_energy; v0_shell = k.v0_shell; v0_line = k.v0_line;
                 w_owner = k.owner; w_item = k.item; w_q = k.q; w_used = k.used; w_avail = k.avail; w_head = k.head;
                 my_visits = k.visits; v_fast = (k.flags & 1) != 0; screening = (k.flags & 2) != 0;
-                w_x.tau = k.x_tau; w_x.e = k.x_e; w_x.k = k.x_k;
                 tracing = true;
                 v_parked = false;
             }
@@ -1680,7 +1642,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             tracing = true;
                             screening = P.tau_pfx != nullptr && ((f_pred >> i) & 1u) != 0u;
                             v_margin = 0.0; v0_r = f_r; v0_energy = vs.energy; v0_shell = f_shell; v0_line = f_line;
-                            w_x.e = -1;
                         }
                     }
                     if (tracing) {
@@ -1696,10 +1657,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                             if (st == 1 && (P.debug_flags & 67108864)) vtraced_total += 1ull << 40;  // tests: decided on the prefix sums -> counters[7] >> 40
                             if (st == 2) {  // not decided on the prefix sums: again, line by line
                                 vs.r = v0_r; vs.mu = vs.mu0; vs.energy = v0_energy; vs.tau = 0.0; vs.shell = v0_shell; vs.next_line = v0_line;
-                                my_visits = 0; w_used = 0; screening = false; st = 0; w_x.e = -1;
+                                my_visits = 0; w_used = 0; screening = false; st = 0;
                             }
                         } else
-                            st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, w_x, v_rcp_nu, v_fast, lds_geo, my_visits);
+                            st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, v_rcp_nu, v_fast, lds_geo, my_visits);
                         if (st != 0) {
                             VpResult r;
                             r.nu = vs.nu; r.energy = st == 1 ? vs.energy * mcm::exp(-vs.tau) : 0.0; r.mu0 = vs.mu0;
@@ -1736,7 +1697,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                 k.rcp_nu = v_rcp_nu; k.margin = v_margin; k.v0_r = v0_r; k.v0_energy = v0_energy; k.v0_shell = v0_shell; k.v0_line = v0_line;
                 k.owner = w_owner; k.item = w_item; k.q = w_q; k.used = w_used; k.avail = w_avail; k.head = w_head;
                 k.visits = my_visits; k.flags = (v_fast ? 1 : 0) | (screening ? 2 : 0);
-                k.x_tau = w_x.tau; k.x_e = w_x.e; k.x_k = w_x.k;
                 gstore(W->vp_park + ((size_t)blockIdx.x * 64 + lane), k);
                 v_parked = true;
             }
@@ -2033,8 +1993,6 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
     bool screening = false;
     double v_margin = 0.0, v0_r = 0.0, v0_energy = 0.0;
     int v0_shell = 0, v0_line = 0;
-    VpCross w_x;  // the line-by-line crossing in progress
-    w_x.tau = 0.0; w_x.e = -1; w_x.k = 0;
     for (;;) {
         const unsigned long long free_l = __ballot(!tracing);
         bool take = false;
@@ -2106,7 +2064,6 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
             tracing = true;
             screening = P.tau_pfx != nullptr && ((f_pred >> i) & 1u) != 0u;
             v_margin = 0.0; v0_r = f_r; v0_energy = vs.energy; v0_shell = vs.shell; v0_line = vs.next_line;
-            w_x.e = -1;
         }
         if (tracing) {
             const MC_G double *dr = glob(W->vq_req + my_slot)->draws;
@@ -2121,10 +2078,10 @@ __global__ void __launch_bounds__(64) vpacket_trace_kernel(const WaveCold *__res
                 st = vp_screen_step<FULL>(P, wdraw, draws_left, vs, v_margin, v_rcp_nu, v_fast, geo, my_visits);
                 if (st == 2) {  // not decided on the prefix sums: again, line by line
                     vs.r = v0_r; vs.mu = vs.mu0; vs.energy = v0_energy; vs.tau = 0.0; vs.shell = v0_shell; vs.next_line = v0_line;
-                    my_visits = 0; w_used = 0; screening = false; st = 0; w_x.e = -1;
+                    my_visits = 0; w_used = 0; screening = false; st = 0;
                 }
             } else
-                st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, w_x, v_rcp_nu, v_fast, geo, my_visits);
+                st = vp_shell_step<FULL>(P, wdraw, draws_left, vs, v_rcp_nu, v_fast, geo, my_visits);
             if (st != 0) {
                 VpResult r;
                 r.nu = vs.nu; r.energy = st == 1 ? vs.energy * mcm::exp(-vs.tau) : 0.0; r.mu0 = vs.mu0;
