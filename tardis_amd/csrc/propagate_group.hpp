@@ -923,7 +923,7 @@ __global__ void __launch_bounds__(BLOCK, OCC) propagate_group_kernel(GroupArgs P
                     }
                     if (VPK) {  // volley at launch (classic/packet_propagation.py:109-118), run in the next volley phase
                         vseq = 0;
-                        pred_bits = 0;
+                        pred_bits = P.tau_pfx ? 0xffffffffu : 0u;  // (screening on: a new packet's first volley is predicted dropped, i.e. screened, too -- see propagate_wave.hpp)
                         want_volley = true;
                     }
                 }

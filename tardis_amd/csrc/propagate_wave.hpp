@@ -422,6 +422,41 @@ struct VpState {
     int shell, next_line;
 };
 
+// The four-line window around the frequency-bucket guess did not pin the first line after `start` whose resonance lies at or beyond the
+// shell boundary (`stops`: monotone along the sorted list): it lies before the window (before_window: stops(w0) held and w0 > start + 1) or
+// beyond it.  The reference walks there line by line (virtual_packet.py:132-150); here FOUR lines per dependent round trip, backwards or
+// forwards -- in a wave every lane waits for the longest of these walks, and with three lines per bucket 22 % of the crossings took
+// one (profiles/r05_bucket_index.txt).  Returns the stopping line, or L when no line stops (a NaN boundary distance: the reference then sums
+// every line).
+template <typename Stops /* bool(int k, double nu_k) */>
+__device__ __forceinline__ int vp_walk_to_stop(const MC_G double *__restrict__ nu_line_g, int L, int start, int w0, bool before_window, Stops &&stops)
+{
+    typedef double nu2 __attribute__((ext_vector_type(2), aligned(8)));
+    auto first_of_four = [&](int b) -> int {  // index 0..3 of the first stopping line among b .. b + 3, 4: none
+        const nu2 a = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)b), c = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)b + 2);
+        const double w[4] = {a.x, a.y, c.x, c.y};
+        int f = 4;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) if (stops(min(b + i, L - 1), w[i])) f = i;
+        return f;
+    };
+    if (before_window) {
+        const int lo = start + 1;
+        int hi = w0;  // stops(hi) holds
+        for (;;) {
+            const int b = max(lo, hi - 4);
+            const int f = first_of_four(b);
+            if (f > 0 || b == lo) return min(b + f, hi);  // (f == 4: none of b .. hi - 1 stops)
+            hi = b;
+        }
+    }
+    for (int b = w0 + 4;; b += 4) {  // (the window w0 .. w0 + 3 did not stop)
+        if (b > L - 1) return L;     // (not even the last line: only with a NaN boundary distance)
+        const int f = first_of_four(b);
+        if (f < 4) return min(b + f, L - 1);
+    }
+}
+
 // one shell crossing of trace_vpacket (:82-244): returns 1 when the v-packet has left the grid / died, 0 to go on, < 0 error.
 // Written branch-light so that the lanes of a wave (each on a different v-packet) stay converged: the stopping line is
 // pinned with a fixed number of predicate evaluations around the frequency-bucket guess (a loop only if that was not
@@ -509,18 +544,9 @@ __device__ __forceinline__ int vp_shell_step(const GroupArgs &P, Draw &&draw, in
             else if (sw[2]) { e = min(w0 + 2, L - 1); stops = true; resolved = true; }
             else if (sw[3]) { e = min(w0 + 3, L - 1); stops = true; resolved = true; }
             else e = min(w0 + 3, L - 1);  // beyond the window
-            if (!resolved) {  // the bucket guess was further off: the reference's walk, forward then backward
-                for (;;) {
-                    d_line = d_line_of(e, nu_line_g[(unsigned)e]);
-                    if (d_boundary <= d_line || e == L - 1) break;
-                    ++e;
-                }
-                stops = d_boundary <= d_line;
-                while (e > start + 1) {
-                    if (!(d_boundary <= d_line_of(e - 1, nu_line_g[(unsigned)(e - 1)]))) break;
-                    --e;
-                    stops = true;
-                }
+            if (!resolved) {  // the bucket guess was further off: the reference's walk, four lines per round trip
+                e = vp_walk_to_stop(nu_line_g, L, start, w0, sw[0], [&](int k, double nl) { return d_boundary <= d_line_of(k, nl); });
+                stops = e < L;
             }
             if (!stops) e = L;  // (the reference then sums every line)
         }
@@ -634,20 +660,9 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
 #pragma unroll
                 for (int i = 1; i < 4; ++i) if (hit == i) pe = wp[i];
                 seg = pe - p_start;
-            } else {  // the bucket guess was further off: the reference's walk, forward then backward
-                e = sw[0] ? w0 : min(w0 + 3, L - 1);
-                for (;;) {
-                    d_line = d_line_of(e, nu_line_g[(unsigned)e]);
-                    if (d_boundary <= d_line || e == L - 1) break;
-                    ++e;
-                }
-                bool stops = d_boundary <= d_line;
-                while (e > start + 1) {
-                    if (!(d_boundary <= d_line_of(e - 1, nu_line_g[(unsigned)(e - 1)]))) break;
-                    --e;
-                    stops = true;
-                }
-                if (!stops) e = L;
+            } else {  // the bucket guess was further off: the reference's walk, four lines per round trip
+                if (hit >= 0) e = L - 1;  // (the window ran past the list: its last line stops)
+                else e = vp_walk_to_stop(nu_line_g, L, start, w0, sw[0], [&](int k, double nl) { return d_boundary <= d_line_of(k, nl); });
                 seg = prow[(unsigned)min(e, L)] - p_start;
             }
         }
@@ -1403,7 +1418,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3
                         p.shell = 0; p.status = ST_IN_PROCESS;
                         if (TRACK) { trk_count = 0; trk_boundary = 0; trk_any = false; }  // (-1 + the initial track_boundary_event)
                         state = WS_NEED_TRACE;
-                        if (VPK) { vseq = 0; pred_bits = 0; want_volley = true; }  // volley at launch (classic/packet_propagation.py:109-118)
+                        // volley at launch (classic/packet_propagation.py:109-118).  The roulette predictor of a new packet: where the
+                        // screening is on (long line lists on fine grids: nearly every v-packet is dropped by the roulette) its first volley
+                        // is predicted dropped, too -- and therefore screened, and its draw positions come out right at the first attempt:
+                        // -3 % on the configs[4] shape (profiles/r05_vpacket_requests.txt).  Scheduling only: a wrong prediction is re-traced.
+                        // (debug flag 2048: the predictor of rounds 1-4, for A/B)
+                        if (VPK) { vseq = 0; pred_bits = (P.tau_pfx && !(P.debug_flags & 2048)) ? 0xffffffffu : 0u; want_volley = true; }
                     }
                 }
             }

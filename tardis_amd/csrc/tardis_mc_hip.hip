@@ -116,6 +116,7 @@ struct TardisMcContext {
     unsigned cum16_stride = 0;
     bool have_walk_tables = false;
     int bucket_shift = 0, bucket_n = 0;
+    int bucket_lines_permille = 750;  // option: target lines per bucket x 1000 (takes effect in set_opacity)
     long long bucket_kmin = 0;
     bool lines_sorted = true;  // line_list_nu strictly usable by the index-based kernels (non-increasing, positive)
     // estimators: one allocation [J | nubar | vhist | pad | jblue copy0 | edot copy0 | jblue copy1.. | edot copy1..]
@@ -731,6 +732,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "log_tail_split") ctx->log_tail_split = value ? 1 : 0;
     else if (n == "est_pipeline") ctx->est_pipeline = value ? 1 : 0;
     else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
+    else if (n == "bucket_lines_permille") ctx->bucket_lines_permille = (int)std::max<long long>(50, std::min<long long>(value, 16000));
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "est_accumulate") ctx->est_accumulate = value ? 1 : 0;
     else if (n == "log_tail_packets") ctx->log_tail_packets = (int)std::max<long long>(0, std::min<long long>(value, 1000));
@@ -987,14 +989,18 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     for (size_t i = 0; i < L; ++i)
         if (!(o->line_list_nu[i] > 0.0) || (i > 0 && !(o->line_list_nu[i] <= o->line_list_nu[i - 1]))) { ctx->lines_sorted = false; break; }
     if (ctx->lines_sorted)
-    {   // frequency-bucket index over the (descending) line list, ~2-4 lines per bucket
+    {   // frequency-bucket index over the (descending) line list.  Resolution: bucket_lines_permille / 1000 lines per bucket on average
+        // (default 0.75; rounds 1-4: 3).  A v-packet's shell crossing pins its stopping line with a window of four lines from the
+        // bucket's first line: with three lines per bucket 22 % of the crossings missed the window and walked on line by line -- in a wave
+        // of ~36 tracing lanes every step of the volley worker loop then waited for such a walk (profiles/r05_bucket_index.txt); at 0.75
+        // lines per bucket 1.2 % miss, and the walk takes four lines per round trip (vp_walk_to_stop).  The table is 4 bytes per bucket.
         auto bits = [](double x) { uint64_t u; memcpy(&u, &x, 8); return u; };
         const double nu_hi = o->line_list_nu[0], nu_lo = o->line_list_nu[L - 1];
         int mbits = 4;
         if (nu_lo > 0 && nu_hi >= nu_lo) {
             const double binades = std::max(1.0, std::log2(nu_hi / nu_lo));
             const double per_binade = (double)L / binades;
-            while (mbits < 20 && per_binade / (double)(1 << mbits) > 3.0) ++mbits;
+            while (mbits < 22 && per_binade / (double)(1 << mbits) > 1e-3 * (double)ctx->bucket_lines_permille) ++mbits;
         }
         const int shift = 52 - mbits;
         const long long kmin = (long long)(bits(nu_lo > 0 ? nu_lo : 1.0) >> shift), kmax = (long long)(bits(nu_hi > 0 ? nu_hi : 1.0) >> shift);
