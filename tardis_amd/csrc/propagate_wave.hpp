@@ -693,8 +693,11 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
 // XWALK: with the macro-atom walks on the fp64 running sums compiled in (the cooperative group scan and the per-lane search: what the
 // wave kernel runs when the compact walk tables are not used -- debug flags 128 / 8192, cross-checks); the production instantiations
 // leave them out: ~1 100 instructions and two inlined MT19937 refills less.
-template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false, bool XWALK = true>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VPK ? 3 : 4, VPK ? 3 : 4))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
+// WPE: waves per SIMD the instantiation is compiled for (its VGPR budget: 128 at 4, 168 at 3, 256 at 2).  The v-packet instantiations spill
+// 178 VGPRs at 3; where the LDS of a wave (the per-shell arrays of a fine grid) allows no more than eight waves per CU anyway, the host
+// launches the WPE = 2 instantiation: 239 VGPRs, nothing spilled, no scratch.
+template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false, bool XWALK = true, int WPE = (VPK ? 3 : 4)>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     WaveShared &sh = *reinterpret_cast<WaveShared *>(lds_raw);

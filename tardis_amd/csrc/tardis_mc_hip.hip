@@ -116,6 +116,8 @@ struct TardisMcContext {
     unsigned cum16_stride = 0;
     bool have_walk_tables = false;
     int bucket_shift = 0, bucket_n = 0;
+    long long vpk_wave_min_packets = 800000;  // option: calls with v-packets on fine grids take the wave kernel from this many packets on (the group kernel below)
+    int vpk_wide_registers = 1;       // option: the two-waves-per-SIMD v-packet instantiation where LDS bounds the occupancy at eight waves per CU anyway
     int bucket_lines_permille = 750;  // option: target lines per bucket x 1000 (takes effect in set_opacity)
     long long bucket_kmin = 0;
     bool lines_sorted = true;  // line_list_nu strictly usable by the index-based kernels (non-increasing, positive)
@@ -732,6 +734,8 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "log_tail_split") ctx->log_tail_split = value ? 1 : 0;
     else if (n == "est_pipeline") ctx->est_pipeline = value ? 1 : 0;
     else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
+    else if (n == "vpk_wave_min_packets") ctx->vpk_wave_min_packets = std::max<long long>(0, value);
+    else if (n == "vpk_wide_registers") ctx->vpk_wide_registers = value ? 1 : 0;
     else if (n == "bucket_lines_permille") ctx->bucket_lines_permille = (int)std::max<long long>(50, std::min<long long>(value, 16000));
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "est_accumulate") ctx->est_accumulate = value ? 1 : 0;
@@ -1361,7 +1365,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // With the screening the v-packets of such a shape are half of the wave kernel's pass instead of nearly all of it, and its
     // lane-per-packet event code wins once the call is long enough to amortise its drain: 1.39-1.46 vs 1.33 Mpkt/s at 3e6 packets of
     // the configs[4] shape, 0.63 vs 1.10 at 1e6 (profiles/r03_vpacket_screening.txt).
-    const bool vpk_wave = vpk && ((ctx->n_shells <= 30 && ctx->n_lines <= 100000) || (screen_on && ctx->n_packets >= 2500000));
+    // (round 5: with the finer bucket index, the carried walks and the cut-off of the volley phases the wave kernel is ahead from 1e6 packets per call on:
+    // 1.20 vs 1.81 s there, 4.5 vs 12.7 s at 1e7 -- profiles/r05_vpacket_kernel_choice.txt; the threshold was 2.5e6 in round 3)
+    const bool vpk_wave = vpk && ((ctx->n_shells <= 30 && ctx->n_lines <= 100000) || (screen_on && ctx->n_packets >= ctx->vpk_wave_min_packets));
     int variant = ctx->variant >= 0 ? ctx->variant
                                     : ((vpk && c.number_of_vpackets > 32) ? 0 : (vpk ? (vpk_wave ? 2 : 1) : (prefer_lane_sweeps ? 3 : 2)));
     if (ctx->prob_negative && (variant == 2 || variant == 3)) variant = 1;  // (the wave kernel searches the monotone running sums)
@@ -1489,6 +1495,12 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const int GW = ctx->group_size ? ctx->group_size : (ctx->n_lines <= 100000 ? 8 : 16);
             if (lane_sweep) kw = vpk ? TMC_PICKLS(true) : TMC_PICKLS(false);
             else kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
+            // v-packets on a grid so fine that the per-shell LDS arrays leave room for at most eight waves per CU (two per SIMD): the
+            // instantiation compiled for two waves per SIMD -- 239 VGPRs, no spills -- costs no occupancy there (only built for the long-list
+            // width G = 16 without the cross-check walks; option vpk_wide_registers 0 keeps the 168-VGPR one)
+            if (vpk && !lane_sweep && GW == 16 && !xwalk && wave_waves_per_cu <= 8 && ctx->vpk_wide_registers)
+                kw = full ? (trk ? mc::propagate_wave_kernel<true, true, 16, true, false, false, 2> : mc::propagate_wave_kernel<true, false, 16, true, false, false, 2>)
+                          : (trk ? mc::propagate_wave_kernel<false, true, 16, true, false, false, 2> : mc::propagate_wave_kernel<false, false, 16, true, false, false, 2>);
 #undef TMC_PICKLS2
 #undef TMC_PICKW3
 #undef TMC_PICKLS

@@ -17,4 +17,7 @@
 #ifndef K_XWALK
 #define K_XWALK true
 #endif
-template __global__ void mc::propagate_wave_kernel<K_FULL, K_TRACK, K_G, K_VPK, K_LS, K_XWALK>(mc::WaveHot, const mc::WaveCold *);
+#ifndef K_WPE
+#define K_WPE (K_VPK ? 3 : 4)
+#endif
+template __global__ void mc::propagate_wave_kernel<K_FULL, K_TRACK, K_G, K_VPK, K_LS, K_XWALK, K_WPE>(mc::WaveHot, const mc::WaveCold *);
