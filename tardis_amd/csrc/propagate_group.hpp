@@ -394,6 +394,41 @@ struct VpDraws {  // draws of ONE v-packet: position `first` (in doubles after t
 
 constexpr int VP_SUM_BATCH = 16;  // optical depths a lane requests per round trip of a v-packet's per-shell sum
 
+// The four-line window around the frequency-bucket guess did not pin the first line after `start` whose resonance lies at or beyond the
+// shell boundary (`stops`: monotone along the sorted list): it lies before the window (before_window: stops(w0) held and w0 > start + 1) or
+// beyond it.  The reference walks there line by line (virtual_packet.py:132-150); here FOUR lines per dependent round trip, backwards or
+// forwards -- in a wave every lane waits for the longest of these walks, and with three lines per bucket 22 % of the crossings took
+// one (profiles/r05_bucket_index.txt).  Returns the stopping line, or L when no line stops (a NaN boundary distance: the reference then sums
+// every line).
+template <typename Stops /* bool(int k, double nu_k) */>
+__device__ __forceinline__ int vp_walk_to_stop(const MC_G double *__restrict__ nu_line_g, int L, int start, int w0, bool before_window, Stops &&stops)
+{
+    typedef double nu2 __attribute__((ext_vector_type(2), aligned(8)));
+    auto first_of_four = [&](int b) -> int {  // index 0..3 of the first stopping line among b .. b + 3, 4: none
+        const nu2 a = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)b), c = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)b + 2);
+        const double w[4] = {a.x, a.y, c.x, c.y};
+        int f = 4;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) if (stops(min(b + i, L - 1), w[i])) f = i;
+        return f;
+    };
+    if (before_window) {
+        const int lo = start + 1;
+        int hi = w0;  // stops(hi) holds
+        for (;;) {
+            const int b = max(lo, hi - 4);
+            const int f = first_of_four(b);
+            if (f > 0 || b == lo) return min(b + f, hi);  // (f == 4: none of b .. hi - 1 stops)
+            hi = b;
+        }
+    }
+    for (int b = w0 + 4;; b += 4) {  // (the window w0 .. w0 + 3 did not stop)
+        if (b > L - 1) return L;     // (not even the last line: only with a NaN boundary distance)
+        const int f = first_of_four(b);
+        if (f < 4) return min(b + f, L - 1);
+    }
+}
+
 template <bool FULL, int G>
 __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &rng, VpDraws &dr, double r, double mu, double nu,
                                         double &energy, int shell, int next_line, double &tau_out, unsigned &vvisits, const double *geo)
@@ -460,18 +495,9 @@ __device__ __forceinline__ int vp_trace(const GroupArgs &P, const GroupRng<G> &r
                 else if (sw[2]) { e = min(w0 + 2, L - 1); stops = true; resolved = true; }
                 else if (sw[3]) { e = min(w0 + 3, L - 1); stops = true; resolved = true; }
                 else e = min(w0 + 3, L - 1);  // beyond the window
-                if (!resolved) {
-                    // forward to the first line that stops, then back while the previous one stops as well
-                    for (;;) {
-                        if (stops_at(e) || e == L - 1) break;
-                        ++e;
-                    }
-                    stops = stops_at(e);
-                    while (e > start + 1) {
-                        if (!stops_at(e - 1)) break;
-                        --e;
-                        stops = true;
-                    }
+                if (!resolved) {  // the bucket guess was further off: the reference's walk, four lines per round trip
+                    e = vp_walk_to_stop(glob(P.nu_line), L, start, w0, sw[0], stops_at_nu);
+                    stops = e < L;
                 }
                 if (!stops) e = L;  // (only with a NaN/huge boundary distance: the reference then sums every line)
             }
@@ -621,20 +647,9 @@ __device__ __forceinline__ int vp_screen(const GroupArgs &P, const GroupRng<G> &
 #pragma unroll
                     for (int i = 1; i < 4; ++i) if (hit == i) { pe = wp[i]; qe = wq[i]; ne = wn[i]; }
                     seg = pe - p_start; p_next = qe; nl_next = ne;
-                } else {  // the bucket guess was further off (or the window ran past the list): the reference's walk
-                    e = sw[0] ? w0 : min(w0 + 3, L - 1);
-                    bool stops;
-                    for (;;) {
-                        if (stops_at(e) || e == L - 1) break;
-                        ++e;
-                    }
-                    stops = stops_at(e);
-                    while (e > start + 1) {
-                        if (!stops_at(e - 1)) break;
-                        --e;
-                        stops = true;
-                    }
-                    if (!stops) e = L;
+                } else {  // the bucket guess was further off (or the window ran past the list): the reference's walk, four lines per round trip
+                    if (hit >= 0) e = L - 1;  // (the window ran past the list: its last line stops)
+                    else e = vp_walk_to_stop(glob(P.nu_line), L, start, w0, sw[0], stops_at_nu);
                     seg = prow[(unsigned)min(e, L)] - p_start;
                     p_next = nrow[(unsigned)min(e, L)];
                     nl_next = P.nu_line[(unsigned)min(e, L - 1)];

@@ -422,41 +422,6 @@ struct VpState {
     int shell, next_line;
 };
 
-// The four-line window around the frequency-bucket guess did not pin the first line after `start` whose resonance lies at or beyond the
-// shell boundary (`stops`: monotone along the sorted list): it lies before the window (before_window: stops(w0) held and w0 > start + 1) or
-// beyond it.  The reference walks there line by line (virtual_packet.py:132-150); here FOUR lines per dependent round trip, backwards or
-// forwards -- in a wave every lane waits for the longest of these walks, and with three lines per bucket 22 % of the crossings took
-// one (profiles/r05_bucket_index.txt).  Returns the stopping line, or L when no line stops (a NaN boundary distance: the reference then sums
-// every line).
-template <typename Stops /* bool(int k, double nu_k) */>
-__device__ __forceinline__ int vp_walk_to_stop(const MC_G double *__restrict__ nu_line_g, int L, int start, int w0, bool before_window, Stops &&stops)
-{
-    typedef double nu2 __attribute__((ext_vector_type(2), aligned(8)));
-    auto first_of_four = [&](int b) -> int {  // index 0..3 of the first stopping line among b .. b + 3, 4: none
-        const nu2 a = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)b), c = *reinterpret_cast<const MC_G nu2 *>(nu_line_g + (unsigned)b + 2);
-        const double w[4] = {a.x, a.y, c.x, c.y};
-        int f = 4;
-#pragma unroll
-        for (int i = 3; i >= 0; --i) if (stops(min(b + i, L - 1), w[i])) f = i;
-        return f;
-    };
-    if (before_window) {
-        const int lo = start + 1;
-        int hi = w0;  // stops(hi) holds
-        for (;;) {
-            const int b = max(lo, hi - 4);
-            const int f = first_of_four(b);
-            if (f > 0 || b == lo) return min(b + f, hi);  // (f == 4: none of b .. hi - 1 stops)
-            hi = b;
-        }
-    }
-    for (int b = w0 + 4;; b += 4) {  // (the window w0 .. w0 + 3 did not stop)
-        if (b > L - 1) return L;     // (not even the last line: only with a NaN boundary distance)
-        const int f = first_of_four(b);
-        if (f < 4) return min(b + f, L - 1);
-    }
-}
-
 // one shell crossing of trace_vpacket (:82-244): returns 1 when the v-packet has left the grid / died, 0 to go on, < 0 error.
 // Written branch-light so that the lanes of a wave (each on a different v-packet) stay converged: the stopping line is
 // pinned with a fixed number of predicate evaluations around the frequency-bucket guess (a loop only if that was not

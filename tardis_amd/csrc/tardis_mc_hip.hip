@@ -116,7 +116,7 @@ struct TardisMcContext {
     unsigned cum16_stride = 0;
     bool have_walk_tables = false;
     int bucket_shift = 0, bucket_n = 0;
-    long long vpk_wave_min_packets = 800000;  // option: calls with v-packets on fine grids take the wave kernel from this many packets on (the group kernel below)
+    long long vpk_wave_min_packets = 200000;  // option: calls with v-packets on fine grids take the wave kernel from this many packets on (the group kernel below)
     int vpk_wide_registers = 1;       // option: the two-waves-per-SIMD v-packet instantiation where LDS bounds the occupancy at eight waves per CU anyway
     int bucket_lines_permille = 750;  // option: target lines per bucket x 1000 (takes effect in set_opacity)
     long long bucket_kmin = 0;
@@ -735,7 +735,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "est_pipeline") ctx->est_pipeline = value ? 1 : 0;
     else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
     else if (n == "vpk_wave_min_packets") ctx->vpk_wave_min_packets = std::max<long long>(0, value);
-    else if (n == "vpk_wide_registers") ctx->vpk_wide_registers = value ? 1 : 0;
+    else if (n == "vpk_wide_registers") ctx->vpk_wide_registers = (int)std::max<long long>(0, std::min<long long>(value, 2));
     else if (n == "bucket_lines_permille") ctx->bucket_lines_permille = (int)std::max<long long>(50, std::min<long long>(value, 16000));
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
     else if (n == "est_accumulate") ctx->est_accumulate = value ? 1 : 0;
@@ -1366,7 +1366,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // lane-per-packet event code wins once the call is long enough to amortise its drain: 1.39-1.46 vs 1.33 Mpkt/s at 3e6 packets of
     // the configs[4] shape, 0.63 vs 1.10 at 1e6 (profiles/r03_vpacket_screening.txt).
     // (round 5: with the finer bucket index, the carried walks and the cut-off of the volley phases the wave kernel is ahead from 1e6 packets per call on:
-    // 1.20 vs 1.81 s there, 4.5 vs 12.7 s at 1e7 -- profiles/r05_vpacket_kernel_choice.txt; the threshold was 2.5e6 in round 3)
+    // 1.20 vs 1.81 s there, 4.5 vs 12.7 s at 1e7 -- and still at 3e5, 0.78 vs 1.01 s: profiles/r05_vpacket_kernel_choice.txt; the threshold was 2.5e6 in round 3)
     const bool vpk_wave = vpk && ((ctx->n_shells <= 30 && ctx->n_lines <= 100000) || (screen_on && ctx->n_packets >= ctx->vpk_wave_min_packets));
     int variant = ctx->variant >= 0 ? ctx->variant
                                     : ((vpk && c.number_of_vpackets > 32) ? 0 : (vpk ? (vpk_wave ? 2 : 1) : (prefer_lane_sweeps ? 3 : 2)));
@@ -1498,9 +1498,14 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             // v-packets on a grid so fine that the per-shell LDS arrays leave room for at most eight waves per CU (two per SIMD): the
             // instantiation compiled for two waves per SIMD -- 239 VGPRs, no spills -- costs no occupancy there (only built for the long-list
             // width G = 16 without the cross-check walks; option vpk_wide_registers 0 keeps the 168-VGPR one)
-            if (vpk && !lane_sweep && GW == 16 && !xwalk && wave_waves_per_cu <= 8 && ctx->vpk_wide_registers)
-                kw = full ? (trk ? mc::propagate_wave_kernel<true, true, 16, true, false, false, 2> : mc::propagate_wave_kernel<true, false, 16, true, false, false, 2>)
-                          : (trk ? mc::propagate_wave_kernel<false, true, 16, true, false, false, 2> : mc::propagate_wave_kernel<false, false, 16, true, false, false, 2>);
+            // Measured (profiles/r05_vpk_wide_registers.txt): 3727-3766 vs 4442-4450 ms per 1e7 packets of the configs[4] shape (-16 %).  Option 2 forces
+            // it (then eight waves per CU whatever the LDS allows), 0 keeps the 168-VGPR instantiation.
+            bool wide = vpk && !lane_sweep && !xwalk && (GW == 16 || GW == 8) &&
+                        ((ctx->vpk_wide_registers == 1 && wave_waves_per_cu <= 8) || ctx->vpk_wide_registers == 2);
+#define TMC_PICKWIDE(G_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_, true, false, false, 2> : mc::propagate_wave_kernel<true, false, G_, true, false, false, 2>) \
+                               : (trk ? mc::propagate_wave_kernel<false, true, G_, true, false, false, 2> : mc::propagate_wave_kernel<false, false, G_, true, false, false, 2>))
+            if (wide) kw = GW == 16 ? TMC_PICKWIDE(16) : TMC_PICKWIDE(8);
+#undef TMC_PICKWIDE
 #undef TMC_PICKLS2
 #undef TMC_PICKW3
 #undef TMC_PICKLS
@@ -1514,7 +1519,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const int n_xcd = 8;  // gfx950: 8 XCDs x 32 CUs; the bits of a queue's CU mask are interleaved over the XCDs (bit k -> XCD k % 8)
             const bool cu_split = ctx->pass_cus > 0 && !vq && ctx->log_sets != 1 && cus == 32 * n_xcd && n >= 30000000LL;
             const int cus_prop = cu_split ? cus - n_xcd * ctx->pass_cus : cus;
-            const int waves = (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, (long long)cus_prop * wave_waves_per_cu * (vq ? ctx->vq_oversubscribe : 1)));
+            const int waves = (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, (long long)cus_prop * std::min(wave_waves_per_cu, wide ? 8 : 16) * (vq ? ctx->vq_oversubscribe : 1)));
             // ---- the line-visit log (estimator_log.hpp): two buffer sets, one region per wave; an epoch ends when the regions
             // are full.  Sized for the whole call when that fits log_capacity (1.2x the traces per packet measured in the last
             // call, 128 per packet before anything was measured), else log_capacity.
