@@ -116,7 +116,7 @@ struct TardisMcContext {
     unsigned cum16_stride = 0;
     bool have_walk_tables = false;
     int bucket_shift = 0, bucket_n = 0;
-    long long vpk_wave_min_packets = 200000;  // option: calls with v-packets on fine grids take the wave kernel from this many packets on (the group kernel below)
+    long long vpk_wave_min_packets = 100000;  // option: calls with v-packets on fine grids take the wave kernel from this many packets on (the group kernel below)
     int vpk_wide_registers = 1;       // option: the two-waves-per-SIMD v-packet instantiation where LDS bounds the occupancy at eight waves per CU anyway
     int bucket_lines_permille = 750;  // option: target lines per bucket x 1000 (takes effect in set_opacity)
     long long bucket_kmin = 0;
@@ -1366,7 +1366,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     // lane-per-packet event code wins once the call is long enough to amortise its drain: 1.39-1.46 vs 1.33 Mpkt/s at 3e6 packets of
     // the configs[4] shape, 0.63 vs 1.10 at 1e6 (profiles/r03_vpacket_screening.txt).
     // (round 5: with the finer bucket index, the carried walks and the cut-off of the volley phases the wave kernel is ahead from 1e6 packets per call on:
-    // 1.20 vs 1.81 s there, 4.5 vs 12.7 s at 1e7 -- and still at 3e5, 0.78 vs 1.01 s: profiles/r05_vpacket_kernel_choice.txt; the threshold was 2.5e6 in round 3)
+    // 1.20 vs 1.81 s there, 4.5 vs 12.7 s at 1e7 -- and still at 1e5, 0.63 vs 0.74 s: profiles/r05_vpacket_kernel_choice.txt; the threshold was 2.5e6 in round 3)
     const bool vpk_wave = vpk && ((ctx->n_shells <= 30 && ctx->n_lines <= 100000) || (screen_on && ctx->n_packets >= ctx->vpk_wave_min_packets));
     int variant = ctx->variant >= 0 ? ctx->variant
                                     : ((vpk && c.number_of_vpackets > 32) ? 0 : (vpk ? (vpk_wave ? 2 : 1) : (prefer_lane_sweeps ? 3 : 2)));
