@@ -179,6 +179,13 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
  * "walk_hot_min_mass_long", default 400) of the block on average over the shells; 0 none; 1 every block; all three take effect
  * at the next tardis_mc_set_opacity), "drain_split" (1: the drain of a call runs as a launch of its own beside the estimator passes of
  * what was logged before it; measured, off by default),
+ * "vp_carry_min_active" (pooled v-packet volleys of the wave-owner kernel: a volley phase ends once every v-packet of the round has been handed
+ * to a lane and at most this many lanes still trace; those keep their v-packets for the next pass; default 16, 0: a phase runs to its end),
+ * "bucket_lines_permille" (resolution of the frequency-bucket index of the line list, lines per bucket x 1000; default 750; takes effect at the
+ * next tardis_mc_set_opacity), "vpk_wide_registers" (1, the default: v-packet calls on grids whose per-shell LDS arrays allow at most eight
+ * waves per CU run the instantiation compiled for two waves per SIMD -- 239 VGPRs, no spills; 0 never; 2 always),
+ * "vpk_wave_min_packets" (v-packet calls on fine grids take the wave-owner kernel from this many packets on, the group kernel below; default
+ * 100000), "pass_cus" (CUs per XCD set aside for the line-estimator passes through CU-masked streams; default 0 = off: measured, never pays),
  * "debug_flags" (profiling experiments / cross-checks only: 1 skips the j_blue/Edotlu updates, 2 the J/nu_bar updates, 128
  * walks the macro atom by a per-lane search in the fp64 running sums, 8192 by the cooperative group scan; tests: 16384 counts
  * the jumps out of blocks longer than one window of the compact walk tables into counters[7], 32768 the jumps decided by the
@@ -186,7 +193,10 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
  * tables, 67108864 the v-packets decided by the screening into counters[7] >> 40;
  * diagnostics of a call's drain: 2097152 / 4194304 / 8388608 sum, per wave and from the pass in which its packet supply ran out,
  * the 10-ns ticks to its end / its passes / its live lanes over those passes into counters[7]; 16777216 restores the fixed
- * cut-offs of the sweep and walk phases of rounds 1-2; 33554432 switches the v-packet screening off). */
+ * cut-offs of the sweep and walk phases of rounds 1-2; 33554432 switches the v-packet screening off; 134217728 / 268435456 sum the lanes that
+ * traced / the steps of the pooled volleys' worker loop into counters[7]; 2048 starts a new packet's roulette predictor at zero as in rounds
+ * 1-4.  The flags that read a profiling counter or switch an ablation -- 1, 2, 4, 16, 32, 16384 ... 131072, 524288, 2097152 ... 16777216,
+ * 134217728, 268435456 -- make the engine launch the cross-check instantiation of the kernel, which alone carries them). */
 int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value);
 
 /* ---- staged API: inputs resident in HBM, kernels timed separately -------------------------------- */

@@ -270,23 +270,14 @@ __device__ __forceinline__ void sweep_step(const WaveHot &P, SweepSlot &s, const
 // bounds (and the last line of the list, and every line of a trace whose operands are outside mid_range) is evaluated
 // with the reference's own arithmetic by lane_exact_line() in the same step.
 __device__ __forceinline__ int lane_exact_line(const WaveHot &P, int line, double nu_line, double tau_line, double tau_prev, double nu,
-                                               double comov_nu, double chi, double tau_event, double d_boundary, bool fast, double rcp_nu,
-                                               double rcp_chi, double &distance)
-{   // trace_packet's loop body for one line (modes/homologous_rad_packet_transport.py:100-156), as in sweep_step().  The two quotients: this
-    // block runs in nearly every step of the sweep loop for the whole wave (some lane's trace ends), so its two fp64 divisions (~11
-    // instructions each) are Markstein's three-instruction form on the reciprocals the prologue computed once per trace (mc_device.hpp:
-    // exact_div<true> returns the same correctly rounded quotient for operands in mid_range, which `fast` says); plain divisions otherwise
+                                               double comov_nu, double chi, double tau_event, double d_boundary, double &distance)
+{   // trace_packet's loop body for one line (modes/homologous_rad_packet_transport.py:100-156), as in sweep_step(); the two
+    // quotients are plain divisions here (exact_div<true> returns the same correctly rounded values)
     const double tau_incl = tau_prev + tau_line;
-    const double nu_diff = comov_nu - nu_line;
-    double d_cont, q;
-    if (__ballot(!fast) == 0ull) {
-        d_cont = exact_div<true>(tau_event - tau_prev, chi, rcp_chi);
-        q = exact_div<true>(nu_diff, nu, rcp_nu);
-    } else {
-        d_cont = (tau_event - tau_prev) / chi;
-        q = nu_diff / nu;
-    }
+    const double d_cont = (tau_event - tau_prev) / chi;
     const bool is_last = line == P.n_lines - 1;
+    const double nu_diff = comov_nu - nu_line;
+    const double q = nu_diff / nu;
     const bool close = fabs(q) < CLOSE_LINE_THRESHOLD;
     const bool err = !is_last && !close && !(nu_diff >= 0);
     const double d_far = q * C_LIGHT * P.t_exp;
@@ -1727,7 +1718,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 pflags = (fast ? 1 : 0) | ((delta + 1) << 1);
                 if (LS) {
                     sh.d_cont0[lane] = chi_e; sh.d_boundary[lane] = d_boundary;
-                    sh.rcp_nu[lane] = 1.0 / p.nu; sh.rcp_chi[lane] = 1.0 / chi_e;  // (for the exact evaluation of the stopping line, lane_exact_line)
                     s_tau_event = tau_event;
                     s_tau = 0.0; s_line = p.next_line_id; s_row = (unsigned)p.shell * (unsigned)L;
                     s_kp = ((chi_e * P.tc) / p.nu) * (1.0 + 0x1p-40);
@@ -1808,12 +1798,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         double dist;
                         if (line < L) {
                             ++visits;
-                            // (the reciprocals of the prologue live in sh.rcp_nu / sh.rcp_chi through the sweeps of a trace, which may span passes: not
-                            // where the pooled volleys keep their item list over sh.rcp_nu (lane sweeps + v-packets) or the cooperative
-                            // cross-check walk uses both arrays as scratch)
-                            const bool rcp_ok = !(LS && VPK) && (!XWALK || W->P.cum16 != nullptr || W->P.line_interaction_type != 2);
-                            code = lane_exact_line(H, line, f_nu, f_tau, s_tau, p.nu, comov, chi, s_tau_event, d_bound, s_fast && rcp_ok, sh.rcp_nu[lane],
-                                                   sh.rcp_chi[lane], dist);
+                            code = lane_exact_line(H, line, f_nu, f_tau, s_tau, p.nu, comov, chi, s_tau_event, d_bound, dist);
                             if (!code) { s_tau = s_tau + f_tau; ++adv; }
                         } else {
                             // for-else (lines 157-172): the line list is exhausted; next_line_id is left untouched (bit 3)

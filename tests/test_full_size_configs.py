@@ -84,6 +84,15 @@ def test_baseline_config3_at_its_own_1e8_packets(oracle):
         assert_allclose(b.j_blue_estimator[rows], jb_rows, rtol=EST_RTOL)
         assert_allclose(b.edotlu_estimator[rows], ed_rows, rtol=EST_RTOL)
         del b
+        # the CU partition (option pass_cus: propagation and estimator passes on CU-masked streams; measured, never the default): same results
+        eng.set_option("pass_cus", 4)
+        eng.create_blackbody_packets(P, radius, T_INNER, first=0, count=30_000_000)
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        m = eng.get_results(track_last_interaction=False, want_line_estimators=False)
+        eng.set_option("pass_cus", 0)
+        assert eng.last_kernel_times()["launches"] >= 2
+        assert np.array_equal(m.output_nus, out_nu[:30_000_000]) and np.array_equal(m.output_energies, out_e[:30_000_000])
+        del m
         # the first 1e5 packets against the oracle
         n = 100_000
         sub, ref = _sample(eng, oracle, prob, P, n, radius)
