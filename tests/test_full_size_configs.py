@@ -74,7 +74,6 @@ def test_baseline_config3_at_its_own_1e8_packets(oracle):
         eng.reset_estimators(); eng.propagate(); eng.synchronize()
         assert eng.last_kernel_times()["launches"] > launches
         b = eng.get_results(track_last_interaction=False)
-        eng.set_option("log_capacity", 2_500_000_000)
         assert np.array_equal(out_nu, b.output_nus) and np.array_equal(out_e, b.output_energies)
         assert b.counters == counters_a
         assert_allclose(b.j_estimator, j_a, rtol=EST_RTOL)
@@ -90,7 +89,8 @@ def test_baseline_config3_at_its_own_1e8_packets(oracle):
         eng.reset_estimators(); eng.propagate(); eng.synchronize()
         m = eng.get_results(track_last_interaction=False, want_line_estimators=False)
         eng.set_option("pass_cus", 0)
-        assert eng.last_kernel_times()["launches"] >= 2
+        eng.set_option("log_capacity", 2_500_000_000)
+        assert eng.last_kernel_times()["launches"] >= 2  # (2.8e9 records against a log of 1.2e9)
         assert np.array_equal(m.output_nus, out_nu[:30_000_000]) and np.array_equal(m.output_energies, out_e[:30_000_000])
         del m
         # the first 1e5 packets against the oracle
