@@ -117,6 +117,14 @@ struct TardisMcContext {
     bool have_walk_tables = false;
     int bucket_shift = 0, bucket_n = 0;
     long long vpk_wave_min_packets = 100000;  // option: calls with v-packets on fine grids take the wave kernel from this many packets on (the group kernel below)
+    // Two instantiations of the lane-sweep kernel: 128 VGPRs / sixteen waves per CU / eight lines per step (A), and 166 VGPRs / twelve waves per CU /
+    // twelve lines per step (B).  A wins where the steady state dominates (1e8 packets of the configs[2] shape: B +3.8 %), B where the drain of a
+    // call's longest packets does (1.25e7 packets: -11 %; 1e5-1e6 packets of the tardis_example shape: -6 %; profiles/r05_ls_instantiations.txt):
+    // fewer steps per trace shorten the serial chain of a lone packet, and a mostly idle chip does not miss the four waves.  Option
+    // ls_waves_per_simd: 4 = A, 3 = B, 0 (default) = the engine times both on the first calls of a given (packet count, tables) and keeps the
+    // faster one -- a Monte Carlo iteration repeats the same call; per-packet results are bit-identical either way.
+    int ls_waves_per_simd = 0;
+    struct { long long n = -1; int lines = 0, shells = 0, mode = 0, phase = 0, pending = -1, choice = 0; double ms[2] = {0.0, 0.0}; } ls_tune;
     int vpk_wide_registers = 1;       // option: the two-waves-per-SIMD v-packet instantiation where LDS bounds the occupancy at eight waves per CU anyway
     int bucket_lines_permille = 750;  // option: target lines per bucket x 1000 (takes effect in set_opacity)
     long long bucket_kmin = 0;
@@ -735,6 +743,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "est_pipeline") ctx->est_pipeline = value ? 1 : 0;
     else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
     else if (n == "vpk_wave_min_packets") ctx->vpk_wave_min_packets = std::max<long long>(0, value);
+    else if (n == "ls_waves_per_simd") { ctx->ls_waves_per_simd = (value == 3 || value == 4) ? (int)value : 0; ctx->ls_tune.n = -1; }
     else if (n == "vpk_wide_registers") ctx->vpk_wide_registers = (int)std::max<long long>(0, std::min<long long>(value, 2));
     else if (n == "bucket_lines_permille") ctx->bucket_lines_permille = (int)std::max<long long>(50, std::min<long long>(value, 16000));
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
@@ -1276,6 +1285,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     if (!ctx->have_geometry || !ctx->have_opacity || !ctx->have_config || !ctx->have_packets)
         return fail(ctx, TARDIS_MC_ERR_STATE, "set_geometry/set_opacity/set_config/set_packets must precede propagate");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int tune_pending = ctx->ls_tune.pending;  // (the lane-sweep tuner: whether the previous propagate call was one of its timed ones)
+    ctx->ls_tune.pending = -1;
     int rc = ensure_estimators(ctx);
     if (rc) return rc;
     if (!ctx->counters.p) {
@@ -1410,6 +1421,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         mc::DeviceProblem P = make_device_problem(ctx);
         const size_t lds = 2 * (size_t)ctx->n_shells * sizeof(double);
         if (lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
+        ctx->ls_tune.pending = -1;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
         ctx->chunks_timed = 0;
         if (ctx->n_packets > 0) {
@@ -1506,6 +1518,33 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                                : (trk ? mc::propagate_wave_kernel<false, true, G_, true, false, false, 2> : mc::propagate_wave_kernel<false, false, G_, true, false, false, 2>))
             if (wide) kw = GW == 16 ? TMC_PICKWIDE(16) : TMC_PICKWIDE(8);
 #undef TMC_PICKWIDE
+            // which lane-sweep instantiation (see ls_waves_per_simd above): forced by the option, or timed on the first calls of this key
+            bool ls3 = false;
+            if (lane_sweep && !vpk && !xwalk) {
+                auto &tn = ctx->ls_tune;
+                if (ctx->ls_waves_per_simd == 3) ls3 = true;
+                else if (ctx->ls_waves_per_simd == 0 && ctx->pass_cus == 0) {
+                    if (tn.n != ctx->n_packets || tn.lines != ctx->n_lines || tn.shells != ctx->n_shells || tn.mode != c.line_interaction_type) {
+                        tn.n = ctx->n_packets; tn.lines = ctx->n_lines; tn.shells = ctx->n_shells; tn.mode = c.line_interaction_type;
+                        tn.phase = 0; tn.pending = -1; tn.choice = 0;
+                    } else if (tune_pending >= 0 && ctx->timed) {  // the previous call of this key was a timed one: its duration (propagation + passes)
+                        float ms = 0.f;
+                        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+                        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+                        tn.ms[tune_pending] = ms;
+                    }
+                    // call 0: A, not timed (first-call allocations, the log sized from a guess); call 1: A; call 2: B; from call 3 on: the faster
+                    if (tn.phase == 0) { ls3 = false; tn.pending = -1; }
+                    else if (tn.phase == 1) { ls3 = false; tn.pending = 0; }
+                    else if (tn.phase == 2) { ls3 = true; tn.pending = 1; }
+                    else {
+                        if (tn.phase == 3) tn.choice = tn.ms[1] < tn.ms[0] ? 1 : 0;
+                        ls3 = tn.choice == 1; tn.pending = -1;
+                    }
+                    if (tn.phase < 4) ++tn.phase;
+                }
+            }
+            if (ls3) kw = trk ? mc::propagate_wave_kernel<false, true, 16, false, true, false, 3> : mc::propagate_wave_kernel<false, false, 16, false, true, false, 3>;
 #undef TMC_PICKLS2
 #undef TMC_PICKW3
 #undef TMC_PICKLS
@@ -1519,7 +1558,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const int n_xcd = 8;  // gfx950: 8 XCDs x 32 CUs; the bits of a queue's CU mask are interleaved over the XCDs (bit k -> XCD k % 8)
             const bool cu_split = ctx->pass_cus > 0 && !vq && ctx->log_sets != 1 && cus == 32 * n_xcd && n >= 30000000LL;
             const int cus_prop = cu_split ? cus - n_xcd * ctx->pass_cus : cus;
-            const int waves = (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, (long long)cus_prop * std::min(wave_waves_per_cu, wide ? 8 : 16) * (vq ? ctx->vq_oversubscribe : 1)));
+            const int waves = (int)std::max<long long>(1, std::min<long long>((n + 63) / 64, (long long)cus_prop * std::min(wave_waves_per_cu, wide ? 8 : (ls3 ? 12 : 16)) * (vq ? ctx->vq_oversubscribe : 1)));
             // ---- the line-visit log (estimator_log.hpp): two buffer sets, one region per wave; an epoch ends when the regions
             // are full.  Sized for the whole call when that fits log_capacity (1.2x the traces per packet measured in the last
             // call, 128 per packet before anything was measured), else log_capacity.
@@ -2294,6 +2333,7 @@ int tardis_mc_formal_integral(TardisMcContext *ctx, double inner_temperature, co
     HIP_TRY(ctx, hipMemcpyAsync(d_jred, Jred_lu, S * L * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_jblue, Jblue_lu, S * L * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_freq, frequencies, n_nu * 8, hipMemcpyHostToDevice, ctx->stream));
+    ctx->ls_tune.pending = -1;  // (the timing events are reused here: a pending measurement of the lane-sweep tuner is void)
     HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (S * L > 0)
         hipLaunchKernelGGL(mc::fi_exp_tau_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->tau_t.as<double>(), (long long)(S * L), d_exp);
@@ -2406,6 +2446,7 @@ int tardis_mc_debug_microbench(TardisMcContext *ctx, int which, int64_t n_double
     HIP_TRY(ctx, sink.ensure(8));
     HIP_TRY(ctx, hipMemsetAsync(table.p, 0, (size_t)n_doubles * 8, ctx->stream));
     for (int rep = 0; rep < 2; ++rep) {  // first launch warms up
+        ctx->ls_tune.pending = -1;  // (the timing events are reused here: a pending measurement of the lane-sweep tuner is void)
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
         hipLaunchKernelGGL(microbench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, which, table.as<double>(),
                            (long long)n_doubles, iters, sink.as<double>());

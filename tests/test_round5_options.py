@@ -96,3 +96,64 @@ def test_kernel_choice_threshold(thick):
     got, v = _run(prob)                               # the default threshold (1e5): the group kernel
     assert v == 1
     _same(got, ref)
+
+
+# ---- the two instantiations of the lane-sweep kernel (option ls_waves_per_simd: 4 = 128 VGPRs, sixteen waves per CU, eight lines per step; 3 = 166
+# VGPRs, twelve waves per CU, twelve lines per step; 0 = the engine times both on the first calls of a key and keeps the faster)
+
+LS_PROBLEMS = [
+    dict(seed=5, n_packets=40_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch"),
+    dict(seed=6, n_packets=20_000, n_shells=20, n_lines=500_000, line_interaction_type="macroatom", level_sizes="heavy"),
+    dict(seed=7, n_packets=30_000, n_shells=5, n_lines=37, line_interaction_type="scatter"),      # a line list shorter than three chunks
+    dict(seed=8, n_packets=30_000, n_shells=8, n_lines=12, line_interaction_type="downbranch"),   # ... than one twelve-line chunk
+]
+
+
+def _oracle_full(oracle, prob):
+    return oracle.run(prob.packet_collection, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
+                      prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE, n_threads=oracle.max_threads())
+
+
+@pytest.mark.parametrize("wps", [3, 4])
+@pytest.mark.parametrize("kw", LS_PROBLEMS, ids=["tardis_example", "config3-heavy", "37-lines", "12-lines"])
+def test_lane_sweep_instantiations_match_the_oracle(oracle, kw, wps):
+    from tardis_amd import state as st
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(**kw)
+    ref = _oracle_full(oracle, prob)
+    with Engine(0) as eng:
+        eng.set_option("ls_waves_per_simd", wps)
+        eng.set_option("log_capacity", 1 << 19)  # (several launches: lanes are suspended in the middle of twelve-line sweeps and resumed)
+        eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        got = eng.get_results(track_last_interaction=True)
+        assert eng.last_variant() == 3
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    for f in st.LastInteractionTrackers.I64_FIELDS:
+        assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f)), f
+    for f in st.LastInteractionTrackers.F64_FIELDS:
+        assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f), equal_nan=True), f
+    assert_allclose(got.j_estimator, ref.j_estimator, rtol=EST_RTOL)
+    assert_allclose(got.nu_bar_estimator, ref.nu_bar_estimator, rtol=EST_RTOL)
+    assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+    assert_allclose(got.edotlu_estimator, ref.edotlu_estimator, rtol=EST_RTOL)
+    for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
+        assert got.counters[k] == ref.counters[k], k
+
+
+def test_the_engine_choosing_between_them_never_changes_a_result(oracle):
+    """Default (ls_waves_per_simd 0): the first call of a (packet count, tables) key runs instantiation A untimed, the second A, the third B, from
+    the fourth on the faster of the two -- six calls, six identical results."""
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=9, n_packets=300_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+    ref = _oracle_full(oracle, prob)
+    with Engine(0) as eng:
+        eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+        for call in range(6):
+            eng.reset_estimators(); eng.propagate(); eng.synchronize()
+            got = eng.get_results(track_last_interaction=False)
+            assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies), call
+            assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+            assert got.counters["line_visits"] == ref.counters["line_visits"] and got.counters["rng_draws"] == ref.counters["rng_draws"]
