@@ -185,7 +185,9 @@ const char *tardis_mc_last_error(const TardisMcContext *ctx);   /* ctx may be NU
  * next tardis_mc_set_opacity), "vpk_wide_registers" (1, the default: v-packet calls on grids whose per-shell LDS arrays allow at most eight
  * waves per CU run the instantiation compiled for two waves per SIMD -- 239 VGPRs, no spills; 0 never; 2 always),
  * "vpk_wave_min_packets" (v-packet calls on fine grids take the wave-owner kernel from this many packets on, the group kernel below; default
- * 100000), "pass_cus" (CUs per XCD set aside for the line-estimator passes through CU-masked streams; default 0 = off: measured, never pays),
+ * 100000), "ls_waves_per_simd" (which instantiation of the lane-sweep kernel: 4 = 128 VGPRs, sixteen waves per CU, eight lines per step; 3 = 166 VGPRs,
+ * twelve waves per CU, twelve lines per step -- faster where a call is mostly the drain of its longest packets; 0, the default: the engine times both on
+ * the first calls of a (packet count, tables) key and keeps the faster; per-packet results are bit-identical either way), "pass_cus" (CUs per XCD set aside for the line-estimator passes through CU-masked streams; default 0 = off: measured, never pays),
  * "debug_flags" (profiling experiments / cross-checks only: 1 skips the j_blue/Edotlu updates, 2 the J/nu_bar updates, 128
  * walks the macro atom by a per-lane search in the fp64 running sums, 8192 by the cooperative group scan; tests: 16384 counts
  * the jumps out of blocks longer than one window of the compact walk tables into counters[7], 32768 the jumps decided by the
