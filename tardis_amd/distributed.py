@@ -21,6 +21,7 @@ MASTER_ADDR (rank 0 runs on the master node in every torchrun layout).
 from __future__ import annotations
 
 import atexit
+import hashlib
 import os
 import socket
 import struct
@@ -32,6 +33,15 @@ import numpy as np
 
 _HELLO = b"TMCG"
 _CONNECT_TIMEOUT_S = 300.0
+_MAX_MSG_BYTES = 1 << 33  # post-rendezvous messages without a tighter bound of their own (broadcasts): 8 GiB
+
+
+def _hello_token(master_port: int, world: int) -> bytes:
+    """What both ends of a rendezvous connection must present.  (MASTER_PORT, WORLD_SIZE) keeps jobs of one machine apart;
+    ``TARDIS_AMD_CONTROL_TOKEN`` (any string, the same on every rank) adds a shared secret for multi-node launches, where
+    the port is derivable by anybody who can reach MASTER_ADDR."""
+    secret = os.environ.get("TARDIS_AMD_CONTROL_TOKEN", "")
+    return struct.pack("<4sqq", _HELLO, int(master_port), world) + hashlib.sha256(b"tardis_amd control plane\0" + secret.encode()).digest()[:16]
 
 
 def _send_msg(sock: socket.socket, payload: bytes) -> None:
@@ -75,20 +85,22 @@ class ProcessGroup:
         return self.world_size > 1
 
     # -- the one primitive: every rank contributes a message, rank 0 reduces, every rank gets the result
-    def _allreduce_bytes(self, payload: bytes, reduce) -> bytes:
+    def _allreduce_bytes(self, payload: bytes, reduce, max_bytes: int = _MAX_MSG_BYTES) -> bytes:
+        """``max_bytes`` bounds every message of the exchange (contributions and result): a peer that lost framing -- or is
+        not the peer it claimed to be -- costs an error, not an allocation of whatever its first eight bytes say."""
         if not self.is_distributed:
             return reduce([payload])
         if self.rank == 0:
-            parts = [payload] + [_recv_msg(s) for s in self._peers]
+            parts = [payload] + [_recv_msg(s, max_bytes) for s in self._peers]
             out = reduce(parts)
             for s in self._peers:
                 _send_msg(s, out)
             return out
         _send_msg(self._hub, payload)
-        return _recv_msg(self._hub)
+        return _recv_msg(self._hub, max_bytes)
 
     def barrier(self):
-        self._allreduce_bytes(b"", lambda parts: b"")
+        self._allreduce_bytes(b"", lambda parts: b"", max_bytes=0)
 
     def broadcast_bytes(self, payload: bytes | None, src: int = 0) -> bytes | None:
         """The bytes of rank ``src`` on every rank (None travels as None)."""
@@ -100,7 +112,7 @@ class ProcessGroup:
 
     def max_float(self, value: float) -> float:
         out = self._allreduce_bytes(struct.pack("<d", float(value)),
-                                    lambda parts: struct.pack("<d", max(struct.unpack("<d", p)[0] for p in parts)))
+                                    lambda parts: struct.pack("<d", max(struct.unpack("<d", p)[0] for p in parts)), max_bytes=8)
         return struct.unpack("<d", out)[0]
 
     def sum_arrays_(self, arrays):
@@ -118,7 +130,7 @@ class ProcessGroup:
                     acc += np.frombuffer(p, dtype=np.float64)
                 return acc.tobytes()
 
-            out = self._allreduce_bytes(a.tobytes(), reduce)
+            out = self._allreduce_bytes(a.tobytes(), reduce, max_bytes=a.nbytes)
             a[...] = np.frombuffer(out, dtype=np.float64).reshape(a.shape)
         return arrays
 
@@ -205,7 +217,7 @@ def init_from_env(backend: str = "tcp") -> ProcessGroup:
     fixed = os.environ.get("TARDIS_AMD_CONTROL_PORT")
     if not fixed and _multi_node():
         fixed = str(int(master_port) + 1)  # (no shared temp dir / parent pid across nodes: a port every rank can derive)
-    token = struct.pack("<4sqq", _HELLO, int(master_port), world)
+    token = _hello_token(int(master_port), world)
     deadline = time.monotonic() + _CONNECT_TIMEOUT_S
     if rank == 0:
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)

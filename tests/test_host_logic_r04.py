@@ -193,7 +193,18 @@ def test_strangers_on_the_control_port_cost_rank_zero_nothing(monkeypatch):
     s3 = connect()  # says nothing (rank 0 times it out on its own; here it is closed right away)
     s3.close()
     # the real peer
-    token = struct.pack("<4sqq", distributed._HELLO, int(env["MASTER_PORT"]), 2)
+    token = distributed._hello_token(int(env["MASTER_PORT"]), 2)
+    assert token[:20] == struct.pack("<4sqq", distributed._HELLO, int(env["MASTER_PORT"]), 2) and len(token) == 36
+    # a rank of a job with another TARDIS_AMD_CONTROL_TOKEN: right port, right world size, wrong secret
+    monkeypatch.setenv("TARDIS_AMD_CONTROL_TOKEN", "somebody else's job")
+    other = distributed._hello_token(int(env["MASTER_PORT"]), 2)
+    monkeypatch.delenv("TARDIS_AMD_CONTROL_TOKEN")
+    assert other != token and other[:20] == token[:20]
+    s4 = connect()
+    distributed._send_msg(s4, other + struct.pack("<q", 1))
+    s4.settimeout(10.0)
+    assert s4.recv(1) == b""  # rank 0 closed it without an answer
+    s4.close()
     s = connect()
     distributed._send_msg(s, token + struct.pack("<q", 1))
     assert distributed._recv_msg(s, max_bytes=len(token)) == token
@@ -208,6 +219,19 @@ def test_strangers_on_the_control_port_cost_rank_zero_nothing(monkeypatch):
     assert distributed._recv_msg(s) == b""
     th.join(timeout=30)
     assert not th.is_alive()
+    # after the rendezvous every exchange is bounded by what it can legitimately carry: a peer that lost framing raises
+    err = {}
+
+    def reduce_once():
+        try:
+            result[0].max_float(1.0)
+        except ConnectionError as e:
+            err["e"] = e
+    th = threading.Thread(target=reduce_once)
+    th.start()
+    s.sendall(struct.pack("<Q", 1 << 40))
+    th.join(timeout=30)
+    assert not th.is_alive() and "at most 8 bytes" in str(err["e"])
     s.close()
     for p in result[0]._peers:
         p.close()
