@@ -1776,19 +1776,58 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     const double comov = p.nu * dop;
                     // lines that provably do not stop the trace (see above); the first one that might is kept in f_nu / f_tau
                     const int n_fast = L - 1 - s_line;  // lines of the chunk before the last line of the list
-                    bool alive = s_fast;
-                    double f_nu = nl[0], f_tau = tl[0];
+                    bool alive;
+                    double f_nu, f_tau;
+                    if constexpr (WPE == 3 && !VPK) {
+                        // Straight-line form (the twelve-line instantiation only): the reference's serial sums of the chunk first (t[k] = optical
+                        // depth in front of line k), then the four bounds of every line -- independent of each other, no exec masking, no branch
+                        // per line -- into one bit per line; the first set bit is the line the loop below would have stopped at (same operands,
+                        // same operations: same decision), and the lines after it cost a few flops nobody reads.  Measured
+                        // (profiles/r05_straight_line_sweep.txt): the sweep loop shrinks from 601 to 448 instructions (SALU 268 -> 134, a branch per
+                        // line -> none); calls that are mostly drain -3.5 % (1.25e7 packets of configs[2]: 572 -> 552 ms), but a full chip +2 ... +4 %
+                        // in BOTH instantiations -- the branch per line skips the rest of a chunk once every lane still sweeping has stopped,
+                        // which late in a sweep phase (a handful of lanes left) is most steps -- so the sixteen-wave instantiation keeps the loop.
+                        double t[CH + 1];
+                        t[0] = s_tau;
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) {
-                        if (alive) {
+                        for (int k = 0; k < CH; ++k) t[k + 1] = t[k] + tl[k];
+                        unsigned fail = 0;
+#pragma unroll
+                        for (int k = CH - 1; k >= 0; --k) {
                             const double X = comov - nl[k];
                             const double x = s_kp * X;
-                            const double D = s_tau_event - s_tau;
-                            const double tau_n = s_tau + tl[k];
-                            const double sum = tau_n + x;
-                            const bool ok = k < n_fast && X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
-                            if (ok) { s_tau = tau_n; ++adv; }
-                            else { alive = false; f_nu = nl[k]; f_tau = tl[k]; }
+                            const double D = s_tau_event - t[k];
+                            const double sum = t[k + 1] + x;
+                            const bool ok = X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
+                            fail = fail + fail + (ok ? 0u : 1u);
+                        }
+                        // (the last line of the list and everything behind it, and every line of a trace outside mid_range, go to the exact evaluation)
+                        fail |= 1u << (s_fast ? min(max(n_fast, 0), CH) : 0);
+                        adv = __builtin_ctz(fail);
+                        alive = adv == CH;
+                        double ts = t[0];
+#pragma unroll
+                        for (int k = 1; k <= CH; ++k)
+                            if (adv >= k) ts = t[k];
+                        s_tau = ts;
+                        // (the stopping line's frequency and optical depth: read again -- the sectors were fetched a moment ago -- instead of
+                        // selected from registers that would have to stay alive for it)
+                        f_nu = pn[alive ? 0 : adv]; f_tau = pt[alive ? 0 : adv];
+                    } else {
+                        alive = s_fast;
+                        f_nu = nl[0]; f_tau = tl[0];
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) {
+                            if (alive) {
+                                const double X = comov - nl[k];
+                                const double x = s_kp * X;
+                                const double D = s_tau_event - s_tau;
+                                const double tau_n = s_tau + tl[k];
+                                const double sum = tau_n + x;
+                                const bool ok = k < n_fast && X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
+                                if (ok) { s_tau = tau_n; ++adv; }
+                                else { alive = false; f_nu = nl[k]; f_tau = tl[k]; }
+                            }
                         }
                     }
                     visits += (unsigned long long)adv;

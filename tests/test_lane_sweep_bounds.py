@@ -109,3 +109,44 @@ def test_line_estimator_term_is_energy_times_nu_line_over_nu():
     c_jb = c_e * inv_nu
     assert np.max(np.abs(c_e * nu_line / e_ref - 1.0)) < 5e-14
     assert np.max(np.abs(c_jb * nu_line / jb_ref - 1.0)) < 5e-14
+
+
+def test_straight_line_chunk_stops_where_the_loop_stops():
+    """The twelve-line instantiation evaluates a chunk without a branch per line (propagate_wave.hpp, lane sweep, `WPE == 3`): serial sums of
+    the chunk first, the four bounds of every line into one bit each, count-trailing-zeros.  Same decision and same carried optical depth as the
+    loop that tests line after line -- on chunks with stops at every position, at the end of the line list, and for traces outside mid_range."""
+    rng = np.random.default_rng(7)
+    CH = 12
+    for trial in range(20_000):
+        comov = 10.0 ** rng.uniform(14.5, 15.5)
+        nl = comov * (1.0 - np.cumsum(10.0 ** rng.uniform(-9, -3, CH)))  # descending line frequencies just red of the packet
+        if trial % 7 == 0:
+            nl[rng.integers(CH)] = comov * (1.0 + 1e-6)                   # a line blue of the packet: X < 0
+        tl = 10.0 ** rng.uniform(-6, 1, CH)
+        s_tau0 = float(rng.choice([0.0, 10.0 ** rng.uniform(-3, 1)]))
+        tau_event = s_tau0 + 10.0 ** rng.uniform(-3, 2)
+        kp = 10.0 ** rng.uniform(-18, -12)
+        xb = (comov - nl[rng.integers(CH)]) * float(rng.choice([0.5, 1.0, 1.0 + 1e-12, 50.0]))
+        n_fast = int(rng.choice([CH + 5, CH, rng.integers(0, CH), -3]))
+        s_fast = bool(rng.random() > 0.05)
+        # the loop
+        alive, adv, s_tau = s_fast, 0, s_tau0
+        for k in range(CH):
+            if alive:
+                X = comov - nl[k]; x = kp * X; D = tau_event - s_tau; tau_n = s_tau + tl[k]; total = tau_n + x
+                if k < n_fast and X >= 0.0 and X < xb and x < D and total <= tau_event:
+                    s_tau = tau_n; adv += 1
+                else:
+                    alive = False
+        # straight-line
+        t = [s_tau0]
+        for k in range(CH):
+            t.append(t[k] + tl[k])
+        fail = 0
+        for k in range(CH - 1, -1, -1):
+            X = comov - nl[k]; x = kp * X; D = tau_event - t[k]; total = t[k + 1] + x
+            ok = X >= 0.0 and X < xb and x < D and total <= tau_event
+            fail = fail + fail + (0 if ok else 1)
+        fail |= 1 << (min(max(n_fast, 0), CH) if s_fast else 0)
+        adv2 = (fail & -fail).bit_length() - 1
+        assert adv2 == adv and t[adv2] == s_tau and (adv2 == CH) == alive, trial
