@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="engine option (tardis_mc_set_option)")
     ap.add_argument("--all-on-device", type=int, default=None, metavar="D",
                     help="every rank uses GPU D instead of GPU LOCAL_RANK (tests of the N > 1 path on a one-GPU box)")
+    ap.add_argument("--require-rccl", type=int, default=None, choices=[0, 1],
+                    help="N > 1: 1 = exit with rc 3 unless the RCCL communicator spans all N ranks and passed its self-check (no host "
+                         "fall-back); default: 1 when every rank has a GPU of its own (LOCAL_RANKs on distinct devices), 0 with --all-on-device")
     ap.add_argument("--dump-estimators", type=str, default=None, metavar="NPZ",
                     help="rank 0 writes the job's (all-reduced) J, nu_bar and per-shell sums of j_blue / Edotlu of the last step")
     args = ap.parse_args()
@@ -179,9 +182,21 @@ def main():
     radius = float(prob.geometry.r_inner[0])
     # rank r owns packets [r P, (r+1) P) of the job's N P-packet black-body draw (device packet source)
     eng.create_blackbody_packets(P * n_gpus, radius, T_INNER, first=pg.rank * P, count=P)
-    rccl_ok = distributed.setup_engine_comm(eng, pg)
-    if not rccl_ok and pg.rank == 0:
-        print("warning: no RCCL communicator; the estimators are summed on the host through the control plane", file=sys.stderr)
+    # rccl_ranks: ranks the RCCL communicator was VERIFIED to sum over before the timed region (setup_engine_comm: the all-reduce of
+    # rank + 1 came back as N (N + 1) / 2 on every rank); 0 = no communicator, the estimators take the host fall-back; N = 1: no collective
+    rccl_ranks = distributed.setup_engine_comm(eng, pg)
+    rccl_ok = rccl_ranks == n_gpus
+    require_rccl = args.require_rccl if args.require_rccl is not None else int(n_gpus > 1 and args.all_on_device is None)
+    if n_gpus > 1 and not rccl_ok:
+        if require_rccl:
+            if pg.rank == 0:
+                print(f"bench.py: the RCCL communicator does not span the {n_gpus} ranks (rccl_ranks = {rccl_ranks}) and --require-rccl is on: "
+                      "no line is printed for a job whose collective would be a host fall-back", file=sys.stderr, flush=True)
+            eng.close()
+            pg.destroy()
+            sys.exit(3)
+        if pg.rank == 0:
+            print("warning: no RCCL communicator; the estimators are summed on the host through the control plane", file=sys.stderr)
 
     def step():
         eng.reset_estimators()
@@ -227,6 +242,7 @@ def main():
         "metric": "packets/sec", "value": value, "unit": "packets/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "rccl_ranks": rccl_ranks if n_gpus > 1 else 1,  # (ranks the estimator all-reduce was verified to span; 0: host fall-back; N = 1: no collective in a step)
         "config": {
             "workload": f"BASELINE configs[{args.config - 1}]: {P} packets/GPU/step, "
                         f"{kw['n_shells']} shells, {kw['n_lines']} lines, {mode}, "
@@ -248,6 +264,14 @@ def main():
         crossings = guarded(traced_crossings, eng) if (screened and n_gpus == 1) else None  # (untimed: after the steps)
         out["roofline"] = roofline_block(eng, counters, ktimes, last_ms, P, measured_traffic(args, P, max(ktimes["launches"], 1)),
                                          screened=screened, crossings=crossings if isinstance(crossings, float) else None)
+        # "report both" -- the nominal HBM peak (`peak`) and what THIS box streams (`peak_measured`: a wide coalesced copy over
+        # 2 GiB, tardis_mc_debug_microbench 15; the guide measured 6.29 TB/s), with the dominant kernel's fraction of either
+        pm = guarded(measured_stream_peak, eng)
+        if isinstance(pm, float):
+            out["roofline"]["peak_measured"] = pm
+            out["roofline"]["frac_of_measured"] = out["roofline"]["achieved"] / pm
+        else:
+            out["roofline"]["peak_measured"] = pm
         if n_gpus == 1:
             # (the legs below never take the headline line down with them: a failure is reported in their place)
             n_cpu = args.cpu_sample if args.cpu_sample is not None else default_cpu_sample(kw)
@@ -351,17 +375,26 @@ def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, tr
                                **({"vpacket_crossings_traced": crossings / max(P, 1)} if crossings else {}))}
 
 
+def measured_stream_peak(eng) -> float:
+    """GB/s of a wide coalesced device-to-device copy on this box (16 bytes per lane and access, 2 GiB table, four passes; read + written
+    bytes over the HIP-event time of the second launch): the streaming rate the 8 TB/s spec figure turns into on the hardware at hand."""
+    n, iters = 1 << 28, 4
+    ms = eng.debug_microbench(15, n, iters, 256 * 16)
+    return float(n) * 8.0 * iters / (ms * 1e-3) / 1e9
+
+
 def traced_crossings(eng):
     """Shell crossings the pooled volleys of the wave kernel traced in one call (incl. re-traced ones): one more untimed call of the
     same work with the kernel's profiling counter on (debug flag 134217728 -> counters["reserved"]); None on other kernels."""
     if eng.last_variant() not in (2, 3):
         return None
-    eng.set_option("debug_flags", 134217728)
+    before = eng.options.get("debug_flags", 0)  # (a user's --option debug_flags=... survives the counting call)
+    eng.set_option("debug_flags", before | 134217728)
     try:
         eng.reset_estimators(); eng.propagate(); eng.synchronize()
         return float(eng.last_counters()["reserved"])
     finally:
-        eng.set_option("debug_flags", 0)
+        eng.set_option("debug_flags", before)
 
 
 def extra_leg(device: int, name: str, kw: dict, P: int, steps: int, warmup: int, level_sizes: str, cpu_sample: int, track: bool) -> dict:
@@ -389,7 +422,8 @@ def extra_leg(device: int, name: str, kw: dict, P: int, steps: int, warmup: int,
     last_ms, ktimes, counters = eng.last_propagate_ms(), eng.last_kernel_times(), eng.last_counters()
     sizes = np.diff(prob.opacity_state.macro_block_edge_index)
     screened = kw.get("n_vpackets", 0) > 0 and kw["n_lines"] >= 2500 * kw["n_shells"]
-    crossings = traced_crossings(eng) if screened else None
+    crossings = guarded(traced_crossings, eng) if screened else None
+    crossings = crossings if isinstance(crossings, float) else None
     leg = {"workload": f"{name}: {P} packets/step, {kw['n_shells']} shells, {kw['n_lines']} lines, {kw['line_interaction_type']}, "
                        f"{kw.get('n_vpackets', 0)} v-packets, tracking {'on' if track else 'off'}, macro-atom blocks "
                        f"{level_sizes} (rows per block: median {int(np.median(sizes))}, max {int(sizes.max())})",

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TARDIS_MC_ABI_VERSION 1
+#define TARDIS_MC_ABI_VERSION 2  /* 2 (round 6): + tardis_mc_comm_check, microbench 15 */
 
 enum {
     TARDIS_MC_OK = 0,
@@ -301,6 +301,9 @@ int tardis_mc_comm_init(TardisMcContext *ctx, int rank, int world_size,
                         const uint8_t id[TARDIS_MC_UNIQUE_ID_BYTES]);
 /* In-place sum over ranks of J, nu_bar, j_blue, Edotlu, v-hist (device buffers), on the ctx stream. */
 int tardis_mc_allreduce_estimators(TardisMcContext *ctx);
+/* Self-check of the communicator (call on every rank after tardis_mc_comm_init): a one-element all-reduce of (rank + 1) must
+ * come back as N (N + 1) / 2.  *out_ranks = N on success, 0 otherwise (TARDIS_MC_ERR_COMM / _STATE). */
+int tardis_mc_comm_check(TardisMcContext *ctx, int *out_ranks);
 
 /* ---- diagnostics: element-wise device arithmetic, used by the numerics parity tests ------------------
  * op: 0 x+y, 1 x*y, 2 x/y, 3 sqrt(x), 4 log(x) [engine's portable log], 5 exp(x), 6 x*y+x (un-fused),
@@ -308,7 +311,8 @@ int tardis_mc_allreduce_estimators(TardisMcContext *ctx);
 int tardis_mc_debug_eval(TardisMcContext *ctx, int op, const double *x, const double *y, double *out, int64_t n);
 /* Memory-system micro-benchmarks used to size the kernels (design input): which = 0 random fp64 atomics (agent
  * scope), 1 same at workgroup scope in a per-XCD slice, 2/3 the same with 16 consecutive doubles per 16 lanes,
- * 4 random 8-byte loads, 5 16-lane-coalesced loads.  blocks x 256 threads x iters operations; time in ms. */
+ * 4 random 8-byte loads, 5 16-lane-coalesced loads; 15 a wide coalesced copy of the table's first half onto its second (iters
+ * passes, n_doubles x 8 bytes of traffic each: the box's streaming rate).  blocks x 256 threads x iters operations; time in ms. */
 int tardis_mc_debug_microbench(TardisMcContext *ctx, int which, int64_t n_doubles, int iters, int blocks, double *out_ms);
 
 #ifdef __cplusplus

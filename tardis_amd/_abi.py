@@ -10,7 +10,7 @@ import numpy as np
 
 from . import state as st
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 UNIQUE_ID_BYTES = 128
 N_COUNTERS = 8
 COUNTER_NAMES = ("line_visits", "events", "macro_transitions", "vpacket_line_visits", "vpackets", "rng_draws",

@@ -50,6 +50,7 @@ SYMBOLS = {
     "tardis_mc_comm_get_unique_id": (_i, [_vp]),
     "tardis_mc_comm_init": (_i, [_vp, _i, _i, _vp]),
     "tardis_mc_allreduce_estimators": (_i, [_vp]),
+    "tardis_mc_comm_check": (_i, [_vp, C.POINTER(_i)]),
     "tardis_mc_debug_eval": (_i, [_vp, _i, _vp, _vp, _vp, C.c_int64]),
     "tardis_mc_debug_microbench": (_i, [_vp, _i, C.c_int64, _i, _i, C.POINTER(C.c_double)]),
 }
@@ -76,11 +77,15 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make -C tardis_amd/csrc` (or __graft_entry__.build()). "
                 "There is no CPU fallback for the transport engine.")
         L = C.CDLL(LIB_PATH)
+        L.tardis_mc_abi_version.restype = _i
+        other_build = bool(os.environ.get("TARDIS_MC_LIB"))  # (tools/ A/B against an older build: what it lacks stays unbound)
+        if L.tardis_mc_abi_version() != _abi.ABI_VERSION and not other_build:  # (before the symbols are bound: an older build lacks the newer ones)
+            raise EngineUnavailable(f"{LIB_PATH}: ABI version {L.tardis_mc_abi_version()}, this package needs {_abi.ABI_VERSION}; rebuild it")
         for name, (res, args) in SYMBOLS.items():
+            if other_build and not hasattr(L, name):
+                continue
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
-        if L.tardis_mc_abi_version() != _abi.ABI_VERSION:
-            raise EngineUnavailable("libtardis_mc_hip.so ABI version mismatch; rebuild it")
         _lib = L
     return _lib

@@ -148,6 +148,10 @@ struct GroupArgs {
     // v-packet screening (tau_prefix.hpp): prefix sums of tau along every shell's row, [S][L + 1], and the row totals; null when
     // the screening is off (survival probability > 0, a negative optical depth, debug flag)
     const double *tau_pfx, *tau_rowsum;
+    // interleaved sweep table of the lane sweeps (propagate_wave_kernel<..., NT>): nt_t[shell * nt_stride + line] = {nu_line[line], tau_t[shell][line]};
+    // null / 0 unless the launch uses it
+    const double *nt_t;
+    unsigned nt_stride;
 };
 
 struct Packet {

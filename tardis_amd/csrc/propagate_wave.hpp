@@ -661,9 +661,16 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
 // WPE: waves per SIMD the instantiation is compiled for (its VGPR budget: 128 at 4, 168 at 3, 256 at 2).  The v-packet instantiations spill
 // 178 VGPRs at 3; where the LDS of a wave (the per-shell arrays of a fine grid) allows no more than eight waves per CU anyway, the host
 // launches the WPE = 2 instantiation: 239 VGPRs, nothing spilled, no scratch.
-template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false, bool XWALK = true, int WPE = (VPK ? 3 : 4)>
+// NT (lane-sweep instantiations without v-packets only): the sweep reads the interleaved table nt_t[shell][line] = {nu_line, tau} (16 bytes per
+// line, rows of `nt_stride` entries starting on 128-byte boundaries; H.tau_t points at it) instead of the line list and the shell's tau row:
+// the eight 16-byte loads of a step then come from ONE run of 128 bytes instead of two runs of 64 bytes in two tables.  1: the run starts
+// at the trace's current line (as the separate tables' chunks do); 2: the run is the aligned 128-byte line that holds the current line --
+// a step never straddles two lines, the entries in front of the current line are skipped (the first step of a trace is shorter).
+template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false, bool XWALK = true, int WPE = (VPK ? 3 : 4), int NT = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
+    static_assert(NT == 0 || (LS && !VPK && !FULL), "the interleaved sweep table is read by the lane sweeps only");
+    static_assert(NT != 2 || WPE != 3, "aligned runs are eight lines long");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     WaveShared &sh = *reinterpret_cast<WaveShared *>(lds_raw);
     constexpr size_t SH_BYTES = LS ? WAVE_SHARED_LS_BYTES : sizeof(WaveShared);
@@ -1141,7 +1148,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     const int2 bt = gload(P.blk_tab + nxt_arg);
                     mb0 = bt.x; mb1 = bt.y;
                 } else if (nxt == 3)
-                    emit_nu_walk = glob(P.nu_line)[(unsigned)emit];  // (the sector the coming sweep starts in)
+                    emit_nu_walk = NT != 0 ? glob(P.nt_t)[2u * ((unsigned)p.shell * P.nt_stride + (unsigned)emit)]
+                                           : glob(P.nu_line)[(unsigned)emit];  // (the sector the coming sweep starts in)
             }
             if (in_macro) {  // carried over
                 state = WS_WALK;
@@ -1719,7 +1727,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 if (LS) {
                     sh.d_cont0[lane] = chi_e; sh.d_boundary[lane] = d_boundary;
                     s_tau_event = tau_event;
-                    s_tau = 0.0; s_line = p.next_line_id; s_row = (unsigned)p.shell * (unsigned)L;
+                    s_tau = 0.0; s_line = p.next_line_id; s_row = (unsigned)p.shell * (NT != 0 ? P.nt_stride : (unsigned)L);
                     s_kp = ((chi_e * P.tc) / p.nu) * (1.0 + 0x1p-40);
                     s_xb = ((d_boundary * p.nu) * P.rcp_tc) * (1.0 - 0x1p-40);
                     s_fast = fast && mid_range(s_kp);
@@ -1763,8 +1771,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     // (experiment: twelve lines per step in the 150-VGPR instantiation, option ls_waves_per_simd = 3; the tables carry 16 lines of slack)
                     constexpr int CH = (WPE == 3 && !VPK) ? 12 : LS_CHUNK;
                     double nl[CH], tl[CH];
+                    typedef double nt2 __attribute__((ext_vector_type(2)));
+                    const unsigned nt_at = s_row + (unsigned)s_line;
+                    const nt2 *__restrict__ pq = reinterpret_cast<const nt2 *>(H.tau_t) + (NT == 2 ? (nt_at & ~7u) : nt_at);
+                    const int k0 = NT == 2 ? (int)(nt_at & 7u) : 0;  // entries of the aligned run in front of the current line
+                    if constexpr (NT != 0) {
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) { nl[k] = pn[k]; tl[k] = pt[k]; }
+                        for (int k = 0; k < CH; ++k) { const nt2 e = pq[k]; nl[k] = e.x; tl[k] = e.y; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < CH; ++k) { nl[k] = pn[k]; tl[k] = pt[k]; }
+                    }
                     // (experiment, cross-check instantiations only, debug flag 524288: touch the last optical depth of the NEXT chunk with this
                     // chunk's loads, so that the sibling sector of a 128-byte line is requested together with the first and the next step's
                     // loads find their sectors on the way -- VERDICT r04 "next" 4; profiles/r05_tau_sibling_touch.txt)
@@ -1812,19 +1829,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         s_tau = ts;
                         // (the stopping line's frequency and optical depth: read again -- the sectors were fetched a moment ago -- instead of
                         // selected from registers that would have to stay alive for it)
-                        f_nu = pn[alive ? 0 : adv]; f_tau = pt[alive ? 0 : adv];
+                        if constexpr (NT != 0) { const nt2 e = pq[alive ? 0 : adv]; f_nu = e.x; f_tau = e.y; }
+                        else { f_nu = pn[alive ? 0 : adv]; f_tau = pt[alive ? 0 : adv]; }
                     } else {
                         alive = s_fast;
                         f_nu = nl[0]; f_tau = tl[0];
+                        if constexpr (NT == 2) {  // (a trace outside mid_range evaluates its current line exactly: entry k0 of the run)
+#pragma unroll
+                            for (int k = 1; k < CH; ++k)
+                                if (k == k0) { f_nu = nl[k]; f_tau = tl[k]; }
+                        }
 #pragma unroll
                         for (int k = 0; k < CH; ++k) {
-                            if (alive) {
+                            if (alive && (NT != 2 || k >= k0)) {
                                 const double X = comov - nl[k];
                                 const double x = s_kp * X;
                                 const double D = s_tau_event - s_tau;
                                 const double tau_n = s_tau + tl[k];
                                 const double sum = tau_n + x;
-                                const bool ok = k < n_fast && X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
+                                const bool ok = k - k0 < n_fast && X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
                                 if (ok) { s_tau = tau_n; ++adv; }
                                 else { alive = false; f_nu = nl[k]; f_tau = tl[k]; }
                             }

@@ -124,7 +124,22 @@ struct TardisMcContext {
     // ls_waves_per_simd: 4 = A, 3 = B, 0 (default) = the engine times both on the first calls of a given (packet count, tables) and keeps the
     // faster one -- a Monte Carlo iteration repeats the same call; per-packet results are bit-identical either way.
     int ls_waves_per_simd = 0;
-    struct { long long n = -1; int lines = 0, shells = 0, mode = 0, phase = 0, pending = -1, choice = 0; double ms[2] = {0.0, 0.0}; } ls_tune;
+    // Interleaved sweep table (round 6): nt_t[shell][line] = {nu_line, tau}, 16 bytes per line, rows on 128-byte boundaries -- the eight 16-byte loads of
+    // a lane-sweep step come from one run of 128 bytes instead of two runs of 64 bytes in two tables.  Option sweep_table: 0 the separate tables,
+    // 1 runs from the current line, 2 aligned runs (propagate_wave_kernel<..., NT>); built by the first propagate call after set_opacity that uses it.
+    // -1 (default): 1 under the sixteen-wave instantiation, the separate tables under the twelve-wave one -- measured (profiles/r06_sweep_table.txt):
+    // A 1e8 packets of configs[2] -1.2 ... -1.8 %, 2e7 -4 %, 1.25e7 -6 %, uniform levels -4.5 %, configs[1] -1 %; B +3.5 %; aligned runs (2) +2 ... +6 %
+    // on the heavy-tailed tables (a trace's first step is shorter: 8 % more steps), -5 % on the uniform ones.
+    int sweep_table = -1;
+    DevBuf nt_t;
+    bool nt_valid = false;
+    unsigned nt_stride = 0;
+    // (the tuner: calls 0-4 of a key run A untimed, A, B, A, B -- each timed call with the tuner's OWN event pair, recorded only when the call was
+    // enqueued completely, so that neither another entry point's use of ev_start / ev_stop nor a failed call can leave a stale or unpaired
+    // measurement behind -- and from call 5 on B only if the faster of its two calls beat the faster of A's by >= 3 %: boxes differ by more
+    // than one noisy sample can tell apart)
+    struct { long long n = -1; int lines = 0, shells = 0, mode = 0, table = 0, phase = 0, pending = -1, choice = 0; double ms[2][2] = {{-1.0, -1.0}, {-1.0, -1.0}}; } ls_tune;
+    hipEvent_t ev_tune[2] = {nullptr, nullptr};
     int vpk_wide_registers = 1;       // option: the two-waves-per-SIMD v-packet instantiation where LDS bounds the occupancy at eight waves per CU anyway
     int bucket_lines_permille = 750;  // option: target lines per bucket x 1000 (takes effect in set_opacity)
     long long bucket_kmin = 0;
@@ -252,6 +267,17 @@ __global__ void transpose_kernel(const double *__restrict__ in, double *__restri
     for (int j = threadIdx.y; j < 32; j += 8) {
         long long c = bx + j, r = by + threadIdx.x;
         if (r < rows && c < cols) out[c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+// nt[s * stride + l] = {nu_line[l], tau_t[s][l]} (the interleaved sweep table; entries past a row's L lines and the slack behind the last row: zeros)
+__global__ void __launch_bounds__(256) interleave_kernel(const double *__restrict__ nu_line, const double *__restrict__ tau_t, double2 *__restrict__ nt,
+                                                         long long L, long long S, long long stride, long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long s = i / stride, l = i - s * stride;
+        const bool in = s < S && l < L;
+        nt[i] = in ? make_double2(nu_line[l], tau_t[s * L + l]) : make_double2(0.0, 0.0);
     }
 }
 
@@ -417,6 +443,19 @@ __global__ void microbench_kernel(int which, double *table, long long n, int ite
         else acc += table[idx];
     }
     if (acc == 123.456) sink[0] = acc;
+}
+
+// which = 15: the box's streaming rate -- a wide coalesced copy of the table's first half onto its second (16 bytes per lane and access, grid-stride):
+// n_doubles x 8 bytes cross the memory interface per pass (half read, half written); bench.py reports it as roofline.peak_measured
+__global__ void __launch_bounds__(256) stream_copy_kernel(double *table, long long n, int iters)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const long long half = (n / 4) * 2;  // doubles per half, whole 16-byte pieces
+    const v2d *__restrict__ src = reinterpret_cast<const v2d *>(table);
+    v2d *__restrict__ dst = reinterpret_cast<v2d *>(table + half);
+    const long long pieces = half / 2, step = (long long)gridDim.x * blockDim.x;
+    for (int it = 0; it < iters; ++it)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pieces; i += step) dst[i] = src[i];
 }
 
 // ---- real-packet spectrum and filtered luminosities from the resident per-packet outputs
@@ -688,12 +727,13 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     ctx->li_rec.release();
     ctx->cum16.release(); ctx->rec16.release(); ctx->quad_info.release(); ctx->line_block_c.release();
     ctx->hot_sec.release(); ctx->hot_mass.release(); ctx->hot_flag.release(); ctx->blk_tab.release();
-    ctx->tau_pfx.release(); ctx->tau_rowsum.release(); ctx->pfx_flag.release();
+    ctx->tau_pfx.release(); ctx->tau_rowsum.release(); ctx->pfx_flag.release(); ctx->nt_t.release();
     ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
     ctx->vq_req.release(); ctx->vq_items.release(); ctx->vq_count.release(); ctx->vq_jsave.release();
     if (ctx->suspended_host) (void)hipHostFree(ctx->suspended_host);
     for (hipEvent_t e : ctx->ev_post) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_tune) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->events_host) (void)hipHostFree(ctx->events_host);
@@ -744,6 +784,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
     else if (n == "vpk_wave_min_packets") ctx->vpk_wave_min_packets = std::max<long long>(0, value);
     else if (n == "ls_waves_per_simd") { ctx->ls_waves_per_simd = (value == 3 || value == 4) ? (int)value : 0; ctx->ls_tune.n = -1; }
+    else if (n == "sweep_table") ctx->sweep_table = (int)std::max<long long>(-1, std::min<long long>(value, 2));
     else if (n == "vpk_wide_registers") ctx->vpk_wide_registers = (int)std::max<long long>(0, std::min<long long>(value, 2));
     else if (n == "bucket_lines_permille") ctx->bucket_lines_permille = (int)std::max<long long>(50, std::min<long long>(value, 16000));
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
@@ -885,6 +926,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     ctx->have_hot = false;
     ctx->n_hot_blocks = 0;
     ctx->pfx_valid = false;  // (the prefix sums of the new tau table are built by the first propagate call that traces v-packets)
+    ctx->nt_valid = false;   // (likewise the interleaved sweep table: by the first call that sweeps on it)
     if (macro && E > 1 && !ctx->prob_negative) {
         // compact tables of the per-lane macro-atom walk (walk_tables.hpp): blocks at 16-byte aligned compact offsets.  The walk is
         // bound by the number of memory requests, and a block's window of running sums is fetched in 64-byte sectors: a block of
@@ -1285,8 +1327,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     if (!ctx->have_geometry || !ctx->have_opacity || !ctx->have_config || !ctx->have_packets)
         return fail(ctx, TARDIS_MC_ERR_STATE, "set_geometry/set_opacity/set_config/set_packets must precede propagate");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int tune_pending = ctx->ls_tune.pending;  // (the lane-sweep tuner: whether the previous propagate call was one of its timed ones)
+    const int tune_pending = ctx->ls_tune.pending;  // (the lane-sweep tuner: whether the previous propagate call was one of its timed ones: 2 * instantiation + sample)
     ctx->ls_tune.pending = -1;
+    int tune_slot = -1;  // this call is a timed one of the tuner (becomes ls_tune.pending once it has been enqueued completely)
     int rc = ensure_estimators(ctx);
     if (rc) return rc;
     if (!ctx->counters.p) {
@@ -1421,7 +1464,6 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         mc::DeviceProblem P = make_device_problem(ctx);
         const size_t lds = 2 * (size_t)ctx->n_shells * sizeof(double);
         if (lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
-        ctx->ls_tune.pending = -1;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
         ctx->chunks_timed = 0;
         if (ctx->n_packets > 0) {
@@ -1524,27 +1566,56 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 auto &tn = ctx->ls_tune;
                 if (ctx->ls_waves_per_simd == 3) ls3 = true;
                 else if (ctx->ls_waves_per_simd == 0 && ctx->pass_cus == 0) {
-                    if (tn.n != ctx->n_packets || tn.lines != ctx->n_lines || tn.shells != ctx->n_shells || tn.mode != c.line_interaction_type) {
-                        tn.n = ctx->n_packets; tn.lines = ctx->n_lines; tn.shells = ctx->n_shells; tn.mode = c.line_interaction_type;
-                        tn.phase = 0; tn.pending = -1; tn.choice = 0;
-                    } else if (tune_pending >= 0 && ctx->timed) {  // the previous call of this key was a timed one: its duration (propagation + passes)
+                    if (tn.n != ctx->n_packets || tn.lines != ctx->n_lines || tn.shells != ctx->n_shells || tn.mode != c.line_interaction_type ||
+                        tn.table != ctx->sweep_table) {
+                        tn.n = ctx->n_packets; tn.lines = ctx->n_lines; tn.shells = ctx->n_shells; tn.mode = c.line_interaction_type; tn.table = ctx->sweep_table;
+                        tn.phase = 0; tn.choice = 0;
+                        tn.ms[0][0] = tn.ms[0][1] = tn.ms[1][0] = tn.ms[1][1] = -1.0;
+                    } else if (tune_pending >= 0) {  // the previous call of this key was a timed one: its duration (propagation + passes)
                         float ms = 0.f;
-                        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
-                        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
-                        tn.ms[tune_pending] = ms;
-                    }
-                    // call 0: A, not timed (first-call allocations, the log sized from a guess); call 1: A; call 2: B; from call 3 on: the faster
-                    if (tn.phase == 0) { ls3 = false; tn.pending = -1; }
-                    else if (tn.phase == 1) { ls3 = false; tn.pending = 0; }
-                    else if (tn.phase == 2) { ls3 = true; tn.pending = 1; }
+                        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_tune[1]));
+                        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_tune[0], ctx->ev_tune[1]));
+                        tn.ms[tune_pending >> 1][tune_pending & 1] = ms;
+                    } else if (tn.phase >= 2 && tn.phase <= 5)
+                        tn.phase -= 1;  // the previous phase was a timed call and left no measurement (the call failed half-way): again
+                    // call 0: A, not timed (first-call allocations, the log sized from a guess); calls 1 / 3: A; calls 2 / 4: B; from call 5 on: the choice
+                    if (tn.phase == 0) ls3 = false;
+                    else if (tn.phase <= 4) { ls3 = (tn.phase & 1) == 0; tune_slot = 2 * (ls3 ? 1 : 0) + ((tn.phase - 1) >> 1); }
                     else {
-                        if (tn.phase == 3) tn.choice = tn.ms[1] < tn.ms[0] ? 1 : 0;
-                        ls3 = tn.choice == 1; tn.pending = -1;
+                        if (tn.phase == 5) {
+                            const bool all = tn.ms[0][0] > 0.0 && tn.ms[0][1] > 0.0 && tn.ms[1][0] > 0.0 && tn.ms[1][1] > 0.0;
+                            tn.choice = (all && std::min(tn.ms[1][0], tn.ms[1][1]) < 0.97 * std::min(tn.ms[0][0], tn.ms[0][1])) ? 1 : 0;
+                        }
+                        ls3 = tn.choice == 1;
                     }
-                    if (tn.phase < 4) ++tn.phase;
+                    if (tn.phase < 6) ++tn.phase;
+                    if (tune_slot >= 0)
+                        for (int k = 0; k < 2; ++k)
+                            if (!ctx->ev_tune[k]) HIP_TRY(ctx, hipEventCreate(&ctx->ev_tune[k]));
                 }
             }
             if (ls3) kw = trk ? mc::propagate_wave_kernel<false, true, 16, false, true, false, 3> : mc::propagate_wave_kernel<false, false, 16, false, true, false, 3>;
+            // the interleaved sweep table (option sweep_table; the production lane-sweep instantiations only)
+            int nt_mode = 0;
+            if (lane_sweep && !vpk && !xwalk && (ctx->sweep_table > 0 || (ctx->sweep_table < 0 && !ls3))) {
+                const unsigned long long stride = ((unsigned long long)ctx->n_lines + 7ull) & ~7ull;
+                if (stride * (unsigned long long)ctx->n_shells + 32ull < (1ull << 28)) {
+                    if (!ctx->nt_valid) {
+                        const long long total = (long long)(stride * (unsigned long long)ctx->n_shells) + 32;  // (+ the slack of a step's loads behind the last row)
+                        HIP_TRY(ctx, ctx->nt_t.ensure((size_t)total * 16));
+                        hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 65536)), dim3(256), 0, ctx->stream, ctx->nu_line.as<double>(),
+                                           ctx->tau_t.as<double>(), ctx->nt_t.as<double2>(), (long long)ctx->n_lines, (long long)ctx->n_shells, (long long)stride, total);
+                        HIP_TRY(ctx, hipGetLastError());
+                        ctx->nt_stride = (unsigned)stride;
+                        ctx->nt_valid = true;
+                    }
+                    nt_mode = (ctx->sweep_table == 2 && !ls3) ? 2 : 1;
+                    P.nt_t = ctx->nt_t.as<double>(); P.nt_stride = ctx->nt_stride;
+                    if (ls3) kw = trk ? mc::propagate_wave_kernel<false, true, 16, false, true, false, 3, 1> : mc::propagate_wave_kernel<false, false, 16, false, true, false, 3, 1>;
+                    else if (nt_mode == 2) kw = trk ? mc::propagate_wave_kernel<false, true, 16, false, true, false, 4, 2> : mc::propagate_wave_kernel<false, false, 16, false, true, false, 4, 2>;
+                    else kw = trk ? mc::propagate_wave_kernel<false, true, 16, false, true, false, 4, 1> : mc::propagate_wave_kernel<false, false, 16, false, true, false, 4, 1>;
+                }
+            }
 #undef TMC_PICKLS2
 #undef TMC_PICKW3
 #undef TMC_PICKLS
@@ -1676,6 +1747,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             ctx->wave_cold_host.resize(2);
             hipStream_t st = ctx->stream;
             HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
+            if (tune_slot >= 0) HIP_TRY(ctx, hipEventRecord(ctx->ev_tune[0], st));
             if (cu_masked) {  // everything of this call runs on the masked stream from here on; it is joined to the engine's stream at the end
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_fork_m, ctx->stream));
                 st = ctx->stream_prop_m;
@@ -1696,7 +1768,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             }
             HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[1], st));
             mc::WaveHot hot{};
-            hot.nu_line = P.nu_line; hot.tau_t = P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
+            hot.nu_line = P.nu_line; hot.tau_t = nt_mode ? P.nt_t : P.tau_t; hot.n_lines = P.n_lines; hot.n_shells = P.n_shells;
             hot.disable_line_scattering = P.disable_line_scattering; hot.debug_flags = P.debug_flags;
             hot.t_exp = P.t_exp;
             // cut-offs of the sweep / walk phases (lanes still busy when the wave moves on): 8 / 8 by default.  Where most blocks are
@@ -1986,6 +2058,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->timed = true;
+    if (tune_slot >= 0) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_tune[1], ctx->stream));
+        ctx->ls_tune.pending = tune_slot;
+    }
     return TARDIS_MC_OK;
 }
 
@@ -2007,8 +2083,8 @@ int tardis_mc_progress(TardisMcContext *ctx, int64_t *out_packets_started, int64
     if (ctx->progress_done.load()) { *out_packets_started = total; return TARDIS_MC_OK; }
     if (!ctx->progress_wave.load()) return TARDIS_MC_OK;
     std::lock_guard<std::mutex> lock(ctx->progress_mutex);
+    if (hipSetDevice(ctx->device) != hipSuccess) return TARDIS_MC_ERR_HIP;  // (the polling thread's current device is 0 until it says otherwise)
     if (!ctx->next_packet.p || !ctx->ev_progress_reset || hipEventQuery(ctx->ev_progress_reset) != hipSuccess) return TARDIS_MC_OK;  // (not reset yet)
-    if (hipSetDevice(ctx->device) != hipSuccess) return TARDIS_MC_ERR_HIP;
     if (!ctx->stream_progress && hipStreamCreateWithFlags(&ctx->stream_progress, hipStreamNonBlocking) != hipSuccess) return TARDIS_MC_ERR_HIP;
     if (!ctx->progress_host && hipHostMalloc((void **)&ctx->progress_host, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return TARDIS_MC_ERR_HIP;
     if (hipMemcpyAsync(ctx->progress_host, ctx->next_packet.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream_progress) != hipSuccess ||
@@ -2333,7 +2409,6 @@ int tardis_mc_formal_integral(TardisMcContext *ctx, double inner_temperature, co
     HIP_TRY(ctx, hipMemcpyAsync(d_jred, Jred_lu, S * L * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_jblue, Jblue_lu, S * L * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_freq, frequencies, n_nu * 8, hipMemcpyHostToDevice, ctx->stream));
-    ctx->ls_tune.pending = -1;  // (the timing events are reused here: a pending measurement of the lane-sweep tuner is void)
     HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (S * L > 0)
         hipLaunchKernelGGL(mc::fi_exp_tau_kernel, dim3(2048), dim3(256), 0, ctx->stream, ctx->tau_t.as<double>(), (long long)(S * L), d_exp);
@@ -2415,6 +2490,33 @@ int tardis_mc_allreduce_estimators(TardisMcContext *ctx)
     return TARDIS_MC_OK;
 }
 
+// One-element all-reduce of (rank + 1): every rank must read N (N + 1) / 2 back -- the communicator really spans N ranks and sums.
+__global__ void comm_check_fill_kernel(double *p, double v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+
+int tardis_mc_comm_check(TardisMcContext *ctx, int *out_ranks)
+{
+    if (!ctx || !out_ranks) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    *out_ranks = 0;
+    if (!ctx->comm) return fail(ctx, TARDIS_MC_ERR_STATE, "tardis_mc_comm_init has not been called");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf cell;
+    HIP_TRY(ctx, cell.ensure(sizeof(double)));
+    hipLaunchKernelGGL(comm_check_fill_kernel, dim3(1), dim3(64), 0, ctx->stream, cell.as<double>(), (double)(ctx->rank + 1));
+    hipError_t e = hipGetLastError();
+    int r = e == hipSuccess ? g_rccl.AllReduce(cell.p, cell.p, 1, 8, 0, ctx->comm, ctx->stream) : 0;
+    double got = 0.0;
+    if (e == hipSuccess && r == 0) e = hipMemcpyAsync(&got, cell.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && r == 0) e = hipStreamSynchronize(ctx->stream);
+    cell.release();
+    HIP_TRY(ctx, e);
+    if (r != 0) return fail(ctx, TARDIS_MC_ERR_COMM, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    const double want = 0.5 * (double)ctx->world * (double)(ctx->world + 1);
+    if (got != want)
+        return fail(ctx, TARDIS_MC_ERR_COMM, "communicator self-check: the sum of (rank + 1) over %d ranks came back as %.17g, not %.17g", ctx->world, got, want);
+    *out_ranks = ctx->world;
+    return TARDIS_MC_OK;
+}
+
 /* ---- diagnostics (numerics parity tests) ------------------------------------------------------------- */
 int tardis_mc_debug_eval(TardisMcContext *ctx, int op, const double *x, const double *y, double *out, int64_t n)
 {
@@ -2446,10 +2548,10 @@ int tardis_mc_debug_microbench(TardisMcContext *ctx, int which, int64_t n_double
     HIP_TRY(ctx, sink.ensure(8));
     HIP_TRY(ctx, hipMemsetAsync(table.p, 0, (size_t)n_doubles * 8, ctx->stream));
     for (int rep = 0; rep < 2; ++rep) {  // first launch warms up
-        ctx->ls_tune.pending = -1;  // (the timing events are reused here: a pending measurement of the lane-sweep tuner is void)
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-        hipLaunchKernelGGL(microbench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, which, table.as<double>(),
-                           (long long)n_doubles, iters, sink.as<double>());
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        if (which == 15) hipLaunchKernelGGL(stream_copy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, table.as<double>(), (long long)n_doubles, iters);
+        else hipLaunchKernelGGL(microbench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, which, table.as<double>(),
+                                (long long)n_doubles, iters, sink.as<double>());
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
         HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));

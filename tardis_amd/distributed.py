@@ -281,13 +281,17 @@ def shard_bounds(n_items: int, rank: int, world_size: int) -> tuple[int, int]:
     return (rank * n_items) // world_size, ((rank + 1) * n_items) // world_size
 
 
-def setup_engine_comm(engine, pg: ProcessGroup) -> bool:
-    """Create the RCCL communicator of ``engine`` across the process group (no-op for one process).
+def setup_engine_comm(engine, pg: ProcessGroup) -> int:
+    """Create the RCCL communicator of ``engine`` across the process group and prove that it spans it.
 
-    Returns False -- on every rank -- if the communicator could not be created anywhere (librccl missing, init error); the
-    caller can then reduce the estimators through the control plane (``ProcessGroup.sum_arrays_``) instead of failing."""
+    Returns the number of ranks the communicator was VERIFIED to sum over -- ``pg.world_size`` on success, on every rank: after
+    ``comm_init`` each rank all-reduces a one-element buffer holding rank + 1 and checks N (N + 1) / 2 (``Engine.comm_check``) --
+    and 0, on every rank, if the communicator could not be created or failed its check anywhere (librccl missing, two ranks on one
+    device, init error); the caller may then reduce the estimators through the control plane (``ProcessGroup.sum_arrays_``) -- and
+    has to SAY so: the return value is what a bench line reports as ``rccl_ranks``.  One process: no communicator is needed, and
+    none is created; returns 1 (truthy like the world sizes, and what ``rccl_ranks`` means there: one rank, no collective)."""
     if not pg.is_distributed:
-        return True
+        return 1
     uid = None
     if pg.rank == 0:
         try:
@@ -302,4 +306,11 @@ def setup_engine_comm(engine, pg: ProcessGroup) -> bool:
         except Exception as exc:  # noqa: BLE001
             print(f"tardis_amd.distributed: rank {pg.rank}: RCCL communicator not created ({exc})", flush=True)
             failed = 1.0
-    return pg.max_float(failed) == 0.0
+    if pg.max_float(failed) != 0.0:  # (agreed on BEFORE the check's collective: a rank without a communicator would leave the others hanging in it)
+        return 0
+    try:
+        ok = engine.comm_check() == pg.world_size
+    except Exception as exc:  # noqa: BLE001
+        print(f"tardis_amd.distributed: rank {pg.rank}: RCCL communicator failed its self-check ({exc})", flush=True)
+        ok = False
+    return pg.world_size if pg.max_float(0.0 if ok else 1.0) == 0.0 else 0

@@ -38,6 +38,7 @@ class Engine:
         # the opacity object whose tables are in HBM (None: unknown) -- residency is a property of the ENGINE, which several
         # solvers and the non-resident entry point may share (MCTransportSolverHIP reuses the upload only against this)
         self.resident_opacity = None
+        self.options = {}  # options set through set_option (name -> last value accepted by the library)
 
     # -- lifetime
     def close(self):
@@ -77,6 +78,7 @@ class Engine:
     # -- staged API
     def set_option(self, name: str, value: int):
         self._check(self._L.tardis_mc_set_option(self._h, name.encode(), int(value)), f"set_option({name})")
+        self.options[name] = int(value)
 
     def set_geometry(self, geometry, time_explosion=None):
         m = _abi.marshal_geometry(geometry, time_explosion)
@@ -157,6 +159,35 @@ class Engine:
                                  trackers, cap, want_line_estimators, want_packet_outputs)
         rc = self._L.tardis_mc_get_results(self._h, res.ref())
         self._check(rc, "get_results", int(res.struct.first_error_packet))
+        return res
+
+    def run(self, packet_collection, geometry, time_explosion, opacity_state, montecarlo_configuration, spectrum_frequency_grid,
+            number_of_vpackets=None, track_last_interaction=True, vpacket_log_capacity=None) -> _abi.ResultBuffers:
+        """The one-shot form of the boundary, `tardis_mc_run` (include/tardis_mc.h): geometry, opacity, configuration and packets in,
+        one propagation, results out -- the call a ctypes binding inside `run_classic` makes when nothing is to stay resident
+        (modes/classic/solver.py:223-234).  `vpacket_log_capacity`: entries of the caller's v-packet log arrays for THIS call (None:
+        sized like get_results does; the library restores the context's own setting when the call returns, however it ends)."""
+        mp = _abi.marshal_packets(packet_collection)
+        mg = _abi.marshal_geometry(geometry, time_explosion)
+        mo = _abi.marshal_opacity(opacity_state)
+        mc = _abi.marshal_config(montecarlo_configuration, spectrum_frequency_grid, number_of_vpackets)
+        P, S, L = int(mp.struct.n_packets), int(mg.struct.n_shells), int(mo.struct.n_lines)
+        n_v = int(mc.struct.number_of_vpackets)
+        log = bool(mc.struct.enable_vpacket_tracking) and n_v > 0
+        cap = (int(vpacket_log_capacity) if vpacket_log_capacity is not None else P * n_v * 64) if log else 0
+        trackers = st.LastInteractionTrackers(P) if track_last_interaction else None
+        res = _abi.ResultBuffers(P, S, L, int(mc.struct.n_spectrum_grid), None, None, trackers, cap)
+        self.resident_opacity = None
+        self.results_generation += 1
+        self.estimators_generation += 1
+        self.packets_generation += 1
+        rc = self._L.tardis_mc_run(self._h, mp.ref(), mg.ref(), mo.ref(), mc.ref(), res.ref())
+        self.n_packets, self.n_shells, self.n_lines, self.n_grid = P, S, L, int(mc.struct.n_spectrum_grid)
+        self._n_v, self._vpk_log = n_v, log
+        self._check(rc, "run", int(res.struct.first_error_packet))
+        self.resident_opacity = opacity_state
+        self.results_generation += 1
+        self.estimators_generation += 1
         return res
 
     def create_blackbody_packets(self, n_packets: int, radius: float, temperature: float, base_seed: int = 23111963,
@@ -243,6 +274,12 @@ class Engine:
     def comm_init(self, rank: int, world_size: int, unique_id: bytes):
         buf = (C.c_uint8 * _abi.UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         self._check(self._L.tardis_mc_comm_init(self._h, rank, world_size, buf), "comm_init")
+
+    def comm_check(self) -> int:
+        """Self-check of the RCCL communicator: the one-element all-reduce of (rank + 1) came back as N (N + 1) / 2; returns N."""
+        n = C.c_int(0)
+        self._check(self._L.tardis_mc_comm_check(self._h, C.byref(n)), "comm_check")
+        return int(n.value)
 
     def allreduce_estimators(self):
         self.estimators_generation += 1

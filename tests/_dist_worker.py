@@ -44,10 +44,12 @@ def main():
     assert pg.broadcast_bytes(b"from one" if pg.rank == 1 else None, src=1) == b"from one"
     assert pg.broadcast_bytes(None, src=0) is None
 
-    # communicator set-up: every rank learns the same verdict, whichever rank the failure happens on
+    # communicator set-up: every rank learns the same verdict, whichever rank the failure happens on.  The fake engine's collective runs
+    # over the control plane (a checker standing where RCCL stands): comm_check is Engine.comm_check's contract -- the sum of rank + 1
+    # over the communicator must be N (N + 1) / 2
     class FakeEngine:
-        def __init__(self, fail_uid=False, fail_init_on=None):
-            self.fail_uid, self.fail_init_on, self.inited = fail_uid, fail_init_on, None
+        def __init__(self, fail_uid=False, fail_init_on=None, short_on=None, check_raises_on=None):
+            self.fail_uid, self.fail_init_on, self.short_on, self.check_raises_on, self.inited = fail_uid, fail_init_on, short_on, check_raises_on, None
 
         def comm_unique_id(self):
             if self.fail_uid:
@@ -59,10 +61,24 @@ def main():
                 raise RuntimeError("init failed")
             self.inited = (rank, world_size, uid)
 
+        def comm_check(self):
+            rank, world, _ = self.inited
+            cell = np.array([float(rank + 1)])
+            pg.sum_arrays_([cell])  # (every rank takes part in the collective, as with RCCL)
+            if self.check_raises_on == rank:
+                raise RuntimeError("ncclAllReduce failed")
+            if self.short_on == rank:  # a communicator that reached fewer ranks than the job has (what a silent fall-back would hide)
+                cell[0] = float(rank + 1)
+            if cell[0] != 0.5 * world * (world + 1):
+                raise RuntimeError(f"communicator self-check: sum {cell[0]}")
+            return world
+
     good = FakeEngine()
-    assert distributed.setup_engine_comm(good, pg) is True and good.inited == (pg.rank, 2, b"u" * 128)
-    assert distributed.setup_engine_comm(FakeEngine(fail_uid=True), pg) is False
-    assert distributed.setup_engine_comm(FakeEngine(fail_init_on=1), pg) is False
+    assert distributed.setup_engine_comm(good, pg) == 2 and good.inited == (pg.rank, 2, b"u" * 128)
+    assert distributed.setup_engine_comm(FakeEngine(fail_uid=True), pg) == 0
+    assert distributed.setup_engine_comm(FakeEngine(fail_init_on=1), pg) == 0
+    assert distributed.setup_engine_comm(FakeEngine(short_on=1), pg) == 0
+    assert distributed.setup_engine_comm(FakeEngine(check_raises_on=0), pg) == 0
     pg.barrier()
     np.savez(out_path + f".rank{pg.rank}.npz", lo=lo, hi=hi, output_nus=pc.output_nus[lo:hi],
              output_energies=pc.output_energies[lo:hi], j=est[0], nu_bar=est[1], j_blue=est[2], edotlu=est[3])

@@ -143,15 +143,15 @@ def test_lane_sweep_instantiations_match_the_oracle(oracle, kw, wps):
 
 
 def test_the_engine_choosing_between_them_never_changes_a_result(oracle):
-    """Default (ls_waves_per_simd 0): the first call of a (packet count, tables) key runs instantiation A untimed, the second A, the third B, from
-    the fourth on the faster of the two -- six calls, six identical results."""
+    """Default (ls_waves_per_simd 0): the first call of a (packet count, tables) key runs instantiation A untimed, then A, B, A, B timed, from
+    the sixth on B if its faster call beat A's faster one by 3 % and A otherwise -- eight calls, eight identical results."""
     from tardis_amd.engine import Engine
     prob = synthetic.make_problem(seed=9, n_packets=300_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
     ref = _oracle_full(oracle, prob)
     with Engine(0) as eng:
         eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
         eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
-        for call in range(6):
+        for call in range(8):
             eng.reset_estimators(); eng.propagate(); eng.synchronize()
             got = eng.get_results(track_last_interaction=False)
             assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies), call
