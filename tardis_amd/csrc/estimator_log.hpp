@@ -372,4 +372,178 @@ __global__ void __launch_bounds__(64 * ACCB_WAVES, 8) accumulate_blocks_kernel(c
     }
 }
 
+// accumulate_blocks_kernel with a DYADIC hierarchy of block sums (round 6, option "est_accumulate" 2).  The two-level form above turns a trace of
+// 41 lines into ~11 LDS adds per estimator and is bound by them (ds_add_f64: 11 LDS cycles per wave instruction, serialised further by
+// bank conflicts between the items of different records; LDS 79 % busy, profiles/r04_estimator_partition.txt).  Here the accumulators are a
+// segment tree over the tile -- levels of 1, 2, 4, 8, 16 and 32 lines -- and a record [a, e) adds its two constants to the minimal set of
+// aligned dyadic blocks that tile it: with M the highest-level boundary inside (a, e] (the bits of a and e agree above their highest differing
+// bit d, M = e with the bits below d cleared), the blocks left of M are the set bits of up = M - a from the lowest up, those right of it the
+// set bits of dn = e - M; bits above the top level count as that many 32-line blocks.  41 lines -> ~5.3 adds per estimator.  A line's sum at
+// the flush is the sum of the six accumulators above it.  As before nothing is subtracted anywhere (the terms of a line's sum are the
+// reference's, associated differently; a line nobody visited stays exactly 0) and the per-term arithmetic is unchanged.
+constexpr int ACCD_WAVES = 16;                                 // one workgroup per CU (100 KB of LDS)
+constexpr int ACCD_TILE = EST_TILE + EST_APRON;                // lines in LDS
+constexpr int ACCD_TOP = 5;                                    // top level: blocks of 32 lines
+constexpr int ACCD_CELLS = 2 * ACCD_TILE - ((2 * ACCD_TILE) >> (ACCD_TOP + 1));  // accumulators per estimator: level l (T >> l cells) lives at [2 T - (2 T >> l), ...)
+constexpr int ACCD_LONG = 255;                                 // longer records are walked by the whole wave
+constexpr int ACCD_PASSES = 20;                                // >= 18 = the items of 64 records of ACCD_LONG lines (<= 5 + 8 + 5 each) / 64
+static_assert(ACCD_TILE % (1 << ACCD_TOP) == 0 && EST_TILE % (1 << ACCD_TOP) == 0, "whole top-level blocks, tiles aligned to them");
+
+template <bool FULL, bool DIRECT>
+__global__ void __launch_bounds__(64 * ACCD_WAVES) accumulate_dyadic_kernel(const LineVisitRecord *__restrict__ records,
+                                                                            const unsigned *__restrict__ sorted_index,
+                                                                            const unsigned *__restrict__ bin_start,
+                                                                            const unsigned *__restrict__ slice_start, int n_bins,
+                                                                            int tiles_per_shell, int n_lines, const double *__restrict__ nu_line,
+                                                                            double *__restrict__ jblue_t, double *__restrict__ edot_t)
+{
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ double acc_jb[ACCD_CELLS], acc_ed[ACCD_CELLS];
+    // staged records: the constants; a | up << 11 | dn << 19 (first line relative to the tile, lines left / right of the record's split point); the
+    // record's first item in the batch
+    struct __attribute__((aligned(8))) Staged { double c_e, c_jb; unsigned aud, first; };
+    __shared__ Staged staged[ACCD_WAVES][64];
+    __shared__ unsigned long long starts[ACCD_WAVES][ACCD_PASSES];
+    __shared__ unsigned short nth_bit[32];  // nth_bit[v] >> 3 j & 7: position of the j-th lowest set bit of the 5-bit value v
+    if (threadIdx.x < 32) {
+        unsigned t = 0, k = 0;
+        for (unsigned b = 0; b < 5; ++b)
+            if ((threadIdx.x >> b) & 1u) { t |= b << (3 * k); ++k; }
+        nth_bit[threadIdx.x] = (unsigned short)t;
+    }
+    const unsigned n_slices = slice_start[n_bins];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    auto count_below = [](unsigned long long m) {
+        return (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    };
+    // split of a record [a, a + n), n >= 1: up lines left of M, dn right of it (see above)
+    auto split = [](unsigned a, unsigned n, unsigned &up, unsigned &dn) {
+        const unsigned e = a + n;
+        const unsigned d = 31u - (unsigned)__builtin_clz(a ^ e);  // (a != e)
+        const unsigned M = (e >> d) << d;
+        up = M - a; dn = e - M;
+    };
+    auto n_items = [](unsigned up, unsigned dn) {
+        return (unsigned)__builtin_popcount(up & 31u) + (up >> 5) + (dn >> 5) + (unsigned)__builtin_popcount(dn & 31u);
+    };
+    for (unsigned slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+        int lo = 0, hi = n_bins;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (slice_start[mid] <= slice) lo = mid; else hi = mid;
+        }
+        const int bin = lo;
+        const unsigned rec_first = bin_start[bin] + (slice - slice_start[bin]) * EST_SLICE;
+        const unsigned rec_last = min(bin_start[bin + 1], rec_first + EST_SLICE);
+        const int shell = bin / tiles_per_shell, tile = bin - shell * tiles_per_shell;
+        const unsigned row = (unsigned)shell * (unsigned)n_lines;
+        const unsigned tile_idx0 = row + (unsigned)tile * EST_TILE;
+        const unsigned tile_len = min((unsigned)ACCD_TILE, (unsigned)n_lines - (unsigned)tile * EST_TILE);  // never past the shell's row
+        for (int k = threadIdx.x; k < ACCD_CELLS; k += 64 * ACCD_WAVES) { acc_jb[k] = 0.0; acc_ed[k] = 0.0; }
+        __syncthreads();
+        auto far_line = [&](unsigned o, double c_jb, double c_e) {  // a line past the LDS tile (o: relative to the tile)
+            const double f = FULL ? 1.0 : nu_line[tile_idx0 - row + o];
+            atomic_add_f64(&jblue_t[tile_idx0 + o], c_jb * f);
+            atomic_add_f64(&edot_t[tile_idx0 + o], c_e * f);
+        };
+        // item j of a record {a, up, dn}: the set bits of up & 31 (blocks growing towards M), the 32-line blocks across M, the set bits of dn & 31
+        auto add_item = [&](unsigned a, unsigned up, unsigned dn, unsigned j, double c_jb, double c_e) {
+            const unsigned u5 = up & 31u, d5 = dn & 31u;
+            const unsigned pu = (unsigned)__builtin_popcount(u5), mid = (up >> 5) + (dn >> 5);
+            unsigned level, pos;
+            if (j < pu) {
+                level = ((unsigned)nth_bit[u5] >> (3u * j)) & 7u;
+                pos = a + (u5 & ((1u << level) - 1u));
+            } else if (j - pu < mid) {
+                level = (unsigned)ACCD_TOP;
+                pos = a + u5 + ((j - pu) << ACCD_TOP);
+            } else {
+                level = ((unsigned)nth_bit[d5] >> (3u * (j - pu - mid))) & 7u;
+                pos = a + up + dn - (d5 & ((2u << level) - 1u));
+            }
+            const unsigned last = pos + (1u << level) - 1u;  // the last line the item covers
+            if (last < tile_len) {
+                const unsigned idx = 2u * ACCD_TILE - ((2u * ACCD_TILE) >> level) + (pos >> level);
+                atomicAdd(&acc_jb[idx], c_jb);
+                atomicAdd(&acc_ed[idx], c_e);
+            } else {
+                for (unsigned k = pos; k <= last; ++k) {
+                    if (k < tile_len) { atomicAdd(&acc_jb[k], c_jb); atomicAdd(&acc_ed[k], c_e); }
+                    else far_line(k, c_jb, c_e);
+                }
+            }
+        };
+        auto fetch = [&](unsigned r) {
+            LineVisitRecord rec;
+            rec.c_e = rec.c_jb = 0.0; rec.idx0 = tile_idx0; rec.n = 0;
+            if (r < rec_last) rec = records[DIRECT ? r : sorted_index[r]];
+            return rec;
+        };
+        const unsigned stride = 64 * ACCD_WAVES;
+        unsigned base = rec_first + (unsigned)w * 64;
+        LineVisitRecord next = fetch(base + (unsigned)lane), next2 = fetch(base + stride + (unsigned)lane);  // (16 waves per CU: two batches ahead)
+        for (; base < rec_last; base += stride) {
+            const LineVisitRecord rec = next;
+            next = next2;
+            next2 = fetch(base + 2 * stride + (unsigned)lane);
+            const unsigned n_all = rec.n, a = rec.idx0 - tile_idx0;  // a < EST_TILE
+            unsigned up = 0, dn = 0;
+            if (n_all) split(a, n_all, up, dn);
+            const unsigned m = n_all > (unsigned)ACCD_LONG ? 0u : n_items(up, dn);  // (<= 18 items; long records are handled below)
+            unsigned incl = m;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned upv = (unsigned)__shfl_up((int)incl, off);
+                if (lane >= off) incl += upv;
+            }
+            const unsigned excl = incl - m;
+            const unsigned total = (unsigned)__shfl((int)incl, 63);
+            const unsigned n_pass = (total + 63) >> 6;
+            if (lane < ACCD_PASSES) starts[w][lane] = 0ull;
+            if (m) {  // staged in compacted order: the q-th record that starts is the q-th staged one
+                const unsigned pos = count_below(__ballot(true));
+                Staged st;
+                st.c_e = rec.c_e; st.c_jb = rec.c_jb; st.aud = a | (up << 11) | (dn << 19); st.first = excl;
+                staged[w][pos] = st;
+                atomicOr(&starts[w][excl >> 6], 1ull << (excl & 63));
+            }
+            unsigned rec_base = 0;  // records started before this pass (wave-uniform)
+            for (unsigned i = 0; i < n_pass; ++i) {
+                const unsigned long long mk = starts[w][i];
+                const unsigned t = (i << 6) + (unsigned)lane;
+                if (t < total) {
+                    // the record of item t: the last one that starts at or before it
+                    const unsigned q = rec_base + count_below(mk) + (unsigned)((mk >> lane) & 1ull) - 1u;
+                    const Staged st = staged[w][q];
+                    add_item(st.aud & 0x7ffu, (st.aud >> 11) & 0xffu, st.aud >> 19, t - st.first, st.c_jb, st.c_e);
+                }
+                rec_base += (unsigned)__popcll(mk);
+            }
+            // long records: the whole wave walks the items of one record at a time
+            unsigned long long longs = __ballot(n_all > (unsigned)ACCD_LONG);
+            while (longs) {
+                const int q = __builtin_ctzll(longs);
+                longs &= longs - 1;
+                const unsigned q_a = (unsigned)__shfl((int)a, q), q_up = (unsigned)__shfl((int)up, q), q_dn = (unsigned)__shfl((int)dn, q);
+                const unsigned q_m = n_items(q_up, q_dn);
+                const double l_ce = __shfl(rec.c_e, q), l_cjb = __shfl(rec.c_jb, q);
+                for (unsigned k = lane; k < q_m; k += 64) add_item(q_a, q_up, q_dn, k, l_cjb, l_ce);
+            }
+        }
+        __syncthreads();
+        for (unsigned k = threadIdx.x; k < tile_len; k += 64 * ACCD_WAVES) {
+            const double f = FULL ? 1.0 : nu_line[tile_idx0 - row + k];
+            double v_jb = acc_jb[k], v_ed = acc_ed[k];
+#pragma unroll
+            for (unsigned l = 1; l <= (unsigned)ACCD_TOP; ++l) {
+                const unsigned idx = 2u * ACCD_TILE - ((2u * ACCD_TILE) >> l) + (k >> l);
+                v_jb += acc_jb[idx]; v_ed += acc_ed[idx];
+            }
+            if (v_jb != 0.0) atomic_add_f64(&jblue_t[tile_idx0 + k], v_jb * f);
+            if (v_ed != 0.0) atomic_add_f64(&edot_t[tile_idx0 + k], v_ed * f);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace mc

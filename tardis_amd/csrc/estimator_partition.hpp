@@ -29,10 +29,12 @@ __global__ void __launch_bounds__(256) partition_shell_fill_kernel(const unsigne
     for (int sh = blockIdx.x * 256 + threadIdx.x; sh < n_shells; sh += gridDim.x * 256) shell_fill[sh] = bin_start[sh * tiles_per_shell];
 }
 
-// BY_SHELL: input = the log's chunks (keys: bin keys; region_count / region_capacity), bucket = shell, bucket_fill[n_shells].
-// !BY_SHELL: input = `*total` records in a row, grouped by shell (no keys: the bin follows from the record's first line), bucket = bin,
-//            bucket_fill[n_shells * tiles_per_shell].
-template <bool BY_SHELL>
+// MODE 1 (by shell): input = the log's chunks (keys: bin keys; region_count / region_capacity), bucket = shell, bucket_fill[n_shells].
+// MODE 0: input = `*total` records in a row, grouped by shell (no keys: the bin follows from the record's first line), bucket = bin,
+//         bucket_fill[n_shells * tiles_per_shell].
+// MODE 2 (round 6, the shell-sorted log of propagate_wave_kernel<..., SL>): input = the log's chunks, every chunk holding records of ONE shell;
+//         bucket = bin (the keys), relative to the first bin of the chunk's shell; bucket_fill[n_shells * tiles_per_shell].
+template <int MODE>
 __global__ void __launch_bounds__(PART_THREADS) partition_kernel(const LineVisitRecord *__restrict__ records, const unsigned *__restrict__ keys,
                                                                  const unsigned *__restrict__ region_count, int n_regions, unsigned region_capacity,
                                                                  const unsigned *__restrict__ total, int tiles_per_shell, int n_lines, int key_bits,
@@ -49,9 +51,10 @@ __global__ void __launch_bounds__(PART_THREADS) partition_kernel(const LineVisit
     __shared__ unsigned scratch[PART_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const unsigned segs_per_region = BY_SHELL ? (region_capacity + PART_RECORDS - 1) / PART_RECORDS : 1u;
-    const unsigned n_total = BY_SHELL ? 0u : *total;
-    const unsigned n_segments = BY_SHELL ? (unsigned)n_regions * segs_per_region : (n_total + PART_RECORDS - 1) / PART_RECORDS;
+    constexpr bool BY_SHELL = MODE == 1, CHUNKS = MODE != 0;
+    const unsigned segs_per_region = CHUNKS ? (region_capacity + PART_RECORDS - 1) / PART_RECORDS : 1u;
+    const unsigned n_total = CHUNKS ? 0u : *total;
+    const unsigned n_segments = CHUNKS ? (unsigned)n_regions * segs_per_region : (n_total + PART_RECORDS - 1) / PART_RECORDS;
     auto bin_of = [&](unsigned idx0) {
         const unsigned shell = idx0 / (unsigned)n_lines, start = idx0 - shell * (unsigned)n_lines;
         return shell * (unsigned)tiles_per_shell + start / (unsigned)EST_TILE;
@@ -59,7 +62,7 @@ __global__ void __launch_bounds__(PART_THREADS) partition_kernel(const LineVisit
     for (unsigned seg = blockIdx.x; seg < n_segments; seg += gridDim.x) {
         size_t base;
         unsigned n;
-        if (BY_SHELL) {
+        if (CHUNKS) {
             const unsigned r = seg / segs_per_region, h = seg - r * segs_per_region;
             const unsigned in_region = min(region_count[r], region_capacity);
             const unsigned first = h * PART_RECORDS;
@@ -84,11 +87,12 @@ __global__ void __launch_bounds__(PART_THREADS) partition_kernel(const LineVisit
         // empty shells), the slow way: one global atomic and one scattered write per record
         unsigned first_bucket = 0;
         bool local = true;
-        if (!BY_SHELL) {
+        if (MODE == 0) {
             const unsigned sh0 = (unsigned)rec_w[2] / (unsigned)n_lines, sh1 = (unsigned)rec_w[3 * (n - 1) + 2] / (unsigned)n_lines;  // grouped by shell: first, last
             first_bucket = sh0 * (unsigned)tiles_per_shell;
             local = (sh1 - sh0 + 1u) * (unsigned)tiles_per_shell <= (unsigned)PART_LOCAL_BUCKETS;
         }
+        if (MODE == 2) first_bucket = (keys[base] / (unsigned)tiles_per_shell) * (unsigned)tiles_per_shell;  // (one shell per chunk; the host checks tiles_per_shell <= PART_LOCAL_BUCKETS)
         if (!local) {
             for (unsigned i = tid; i < n; i += PART_THREADS) {
                 const unsigned pos = atomicAdd(&bucket_fill[bin_of((unsigned)rec_w[3 * i + 2])], 1u);
@@ -104,7 +108,7 @@ __global__ void __launch_bounds__(PART_THREADS) partition_kernel(const LineVisit
             const unsigned i = i0 + (unsigned)lane;
             const bool valid = i < n;
             unsigned k = 0;
-            if (valid) k = BY_SHELL ? keys[base + i] / (unsigned)tiles_per_shell : bin_of((unsigned)rec_w[3 * i + 2]) - first_bucket;
+            if (valid) k = BY_SHELL ? keys[base + i] / (unsigned)tiles_per_shell : (MODE == 2 ? keys[base + i] : bin_of((unsigned)rec_w[3 * i + 2])) - first_bucket;
             unsigned long long peers = __ballot(valid);
             for (int b = 0; b < key_bits; ++b) {
                 const bool bit = (k >> b) & 1u;

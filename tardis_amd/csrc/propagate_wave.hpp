@@ -38,6 +38,9 @@ enum : int { WS_NEED_PACKET = 0, WS_NEED_TRACE = 1, WS_SWEEP = 2, WS_DONE = 3, W
                                                                                                               // WS_VOLLEY: a round of the packet's volley is with the v-packet tracer (volley queue); WS_VCARRY: a round of its pooled volley was
                                                                                                               // carried over to the next pass (VpPark)
 constexpr int RES_PENDING = -1;
+// debug_flags bits that read the kernel's profiling / test counters or ablation switches: those are only compiled into the cross-check instantiations (XWALK, the
+// `DBG` constant of propagate_wave_kernel), so the host launches one of those whenever any of these bits is set -- ONE list for both sides
+constexpr int WV_DBG_FLAGS = 1 | 2 | 4 | 16 | 32 | 16384 | 32768 | 65536 | 131072 | 524288 | 2097152 | 4194304 | 8388608 | 16777216 | 134217728 | 268435456;
 constexpr int WV_RESERVE = 32;  // packets a wave reserves per atomic on the chunk's packet counter
 
 // per-wave LDS, structure of arrays indexed by lane
@@ -57,11 +60,12 @@ struct WaveSharedFull {  // only read by the full-relativity sweep
     double r[64], mu[64];
 };
 
-template <bool FULL, bool VPK, bool LS = false>
+template <bool FULL, bool VPK, bool LS = false, bool SL = false>
 __host__ __device__ constexpr size_t wave_kernel_lds_bytes(int n_shells)
 {
     return (LS ? WAVE_SHARED_LS_BYTES : sizeof(WaveShared)) + (FULL ? sizeof(WaveSharedFull) : 0) + (size_t)(VPK ? WV_RING_VPK : WV_RING) * 64 * sizeof(double) +
-           (size_t)(VPK ? 6 : 5) * (size_t)n_shells * sizeof(double);  // J, nu_bar, r_inner, r_outer, n_e (+ the tau row sums of the v-packet screening)
+           (size_t)(VPK ? 6 : 5) * (size_t)n_shells * sizeof(double) +  // J, nu_bar, r_inner, r_outer, n_e (+ the tau row sums of the v-packet screening)
+           (SL ? (size_t)n_shells * 2 * sizeof(unsigned) : 0);          // the open log chunk of every shell and its fill (shell-sorted log)
 }
 
 // result of one (possibly speculative) v-packet trace, handed from the worker lane to the owner lane through global scratch
@@ -666,10 +670,15 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
 // the eight 16-byte loads of a step then come from ONE run of 128 bytes instead of two runs of 64 bytes in two tables.  1: the run starts
 // at the trace's current line (as the separate tables' chunks do); 2: the run is the aligned 128-byte line that holds the current line --
 // a step never straddles two lines, the entries in front of the current line are skipped (the first step of a trace is shorter).
-template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false, bool XWALK = true, int WPE = (VPK ? 3 : 4), int NT = 0>
+// SL (shell-sorted log, round 6; n_shells <= 64, no volley queue): a wave keeps one open chunk of the line-visit log PER SHELL (chunk and fill in LDS) and appends
+// a trace's record to the chunk of its shell -- the lanes of a pass that log into the same shell find each other with ballots over the shell's bits, as the
+// partition kernel's lanes do -- so that every chunk of the log holds records of ONE shell and the estimator passes start with the partition by bin: the pass that
+// grouped the log by shell (a full read and write of the log: 21 of the 87 ms of passes per 2e9 records, profiles/r04_estimator_partition.txt) is gone.
+template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false, bool XWALK = true, int WPE = (VPK ? 3 : 4), int NT = 0, bool SL = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
     static_assert(NT == 0 || (LS && !VPK && !FULL), "the interleaved sweep table is read by the lane sweeps only");
+    static_assert(!SL || !VPK, "the shell-sorted log is built for the instantiations without v-packets");
     static_assert(NT != 2 || WPE != 3, "aligned runs are eight lines long");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     WaveShared &sh = *reinterpret_cast<WaveShared *>(lds_raw);
@@ -680,6 +689,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     double *lds_J = ring + RING * 64;
     double *lds_nubar = lds_J + H.n_shells;
     double *lds_geo = lds_nubar + H.n_shells;  // r_inner | r_outer | n_e
+    int *lds_lchunk = reinterpret_cast<int *>(lds_geo + (VPK ? 4 : 3) * H.n_shells);  // SL: the open chunk of every shell (-1: none) ...
+    unsigned *lds_lused = reinterpret_cast<unsigned *>(lds_lchunk + H.n_shells);       // ... and the records appended to it
+    if (SL)
+        for (int s = threadIdx.x; s < H.n_shells; s += 64) { lds_lchunk[s] = -1; lds_lused[s] = 0u; }
     for (int s = threadIdx.x; s < H.n_shells; s += 64) {
         lds_geo[s] = glob(W->P.r_inner)[s]; lds_geo[H.n_shells + s] = glob(W->P.r_outer)[s]; lds_geo[2 * H.n_shells + s] = glob(W->P.n_e)[s];
         if (VPK) lds_geo[3 * H.n_shells + s] = W->P.tau_rowsum ? glob(W->P.tau_rowsum)[s] : 0.0;
@@ -875,7 +888,52 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         double *const jb = P.jblue_t, *const ed = P.edot_t;
         // a pass appends at most 64 records: without room for them the wave takes the next chunk of the pool (one atomic per chunk)
         bool log_full = false;
-        if (log.region_capacity > 0 && (log_chunk < 0 || log_used + 64 > log.region_capacity) && __ballot(state != WS_DONE) != 0ull) {
+        // SL: the records this pass will append are known here (the lanes whose swept trace passed at least one line), and so are their shells: every
+        // record gets its slot now -- in the open chunk of its shell; a shell's chunk without room for this pass's records is replaced from the pool -- so
+        // that a wave that finds the pool empty suspends before anything of the pass has happened
+        bool sl_log = false;
+        int sl_chunk = -1;
+        unsigned sl_slot = 0;
+        if (SL && log.region_capacity > 0) {
+            if (state == WS_SWEEP && !(LS && s_active)) {
+                const int info = sh.res_info[lane];
+                const int stop_line = (info & 8) ? L : sh.res_line[lane];
+                sl_log = stop_line - p.next_line_id + (((info & 7) == 3) ? 1 : 0) > 0 && !(DBG && (P.debug_flags & 1));
+            }
+            const unsigned long long have = __ballot(sl_log);
+            if (have) {
+                unsigned long long peers = have;  // the lanes that log into this lane's shell
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const bool bit = (p.shell >> b) & 1;
+                    const unsigned long long m = __ballot(sl_log && bit);
+                    peers &= bit ? m : ~m;
+                }
+                unsigned used = 0;
+                if (sl_log) { sl_chunk = lds_lchunk[p.shell]; used = lds_lused[p.shell]; }
+                const int leader = sl_log ? __builtin_ctzll(peers) : 0;
+                const unsigned cnt = (unsigned)__popcll(peers);
+                const bool need = sl_log && lane == leader && (sl_chunk < 0 || used + cnt > log.region_capacity);
+                if (__ballot(need)) {  // (once per chunk and shell)
+                    bool full = false;
+                    if (need) {
+                        if (sl_chunk >= 0) glob(log.region_count)[sl_chunk] = used;
+                        const unsigned c = gatomic_add_u32(log.pool_next, 1u);
+                        if (c < (unsigned)log.n_regions) sl_chunk = (int)c; else { sl_chunk = -1; full = true; }
+                        used = 0;
+                        lds_lchunk[p.shell] = sl_chunk; lds_lused[p.shell] = 0u;
+                    }
+                    log_full = __ballot(full) != 0ull && W->save != nullptr;  // the pool is empty: the epoch is over for this wave
+                    sl_chunk = __shfl(sl_chunk, leader); used = (unsigned)__shfl((int)used, leader);
+                }
+                if (!log_full && sl_log) {
+                    sl_slot = used + (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+                    if (lane == leader) lds_lused[p.shell] = used + cnt;
+                }
+                logged_any = true;
+            }
+        }
+        if (!SL && log.region_capacity > 0 && (log_chunk < 0 || log_used + 64 > log.region_capacity) && __ballot(state != WS_DONE) != 0ull) {
             if (lane == 0 && log_chunk >= 0) glob(log.region_count)[log_chunk] = min(log_used, log.region_capacity);
             unsigned c = 0;
             if (lane == 0) c = gatomic_add_u32(log.pool_next, 1u);
@@ -954,9 +1012,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             // every wave appends to the chunk it holds: no atomics, no empty slots
             const unsigned long long have = __ballot(n_visit > 0);
             if (have) {
-                const unsigned my = log_used + (unsigned)__popcll(have & ((1ull << lane) - 1ull));
-                log_used += (unsigned)__popcll(have);
-                logged_any = true;
+                unsigned my = 0;
+                int my_chunk = log_chunk;
+                if (SL) { my = sl_slot; my_chunk = sl_chunk; }  // (reserved at the top of the pass, in the chunk of the record's shell)
+                else {
+                    my = log_used + (unsigned)__popcll(have & ((1ull << lane) - 1ull));
+                    log_used += (unsigned)__popcll(have);
+                    logged_any = true;
+                }
                 if (n_visit > 0) {
                     LineVisitRecord rec;
                     const double inv_nu = 1.0 / p.nu;
@@ -964,8 +1027,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     rec.c_jb = rec.c_e * inv_nu;
                     rec.idx0 = (unsigned)p.shell * (unsigned)L + (unsigned)start;
                     rec.n = (unsigned)n_visit;
-                    if (log_chunk >= 0 && my < log.region_capacity) {
-                        const size_t slot = (size_t)(unsigned)log_chunk * log.region_capacity + my;
+                    if (my_chunk >= 0 && my < log.region_capacity) {
+                        const size_t slot = (size_t)(unsigned)my_chunk * log.region_capacity + my;
                         gstore(log.records + slot, rec);
                         glob(log.keys)[slot] = (unsigned)(p.shell * log.tiles_per_shell + start / EST_TILE);
                     } else {  // no log (or no chunk to be had and no way to suspend): add the terms directly (slow path)
@@ -1942,7 +2005,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         TMC_SEC(6)
     }
 
-    if (lane == 0 && W->log.region_capacity > 0 && log_chunk >= 0) glob(W->log.region_count)[log_chunk] = min(log_used, W->log.region_capacity);
+    if (!SL && lane == 0 && W->log.region_capacity > 0 && log_chunk >= 0) glob(W->log.region_count)[log_chunk] = min(log_used, W->log.region_capacity);
+    if (SL && W->log.region_capacity > 0)
+        for (int s = lane; s < H.n_shells; s += 64)
+            if (lds_lchunk[s] >= 0) glob(W->log.region_count)[lds_lchunk[s]] = min(lds_lused[s], W->log.region_capacity);
     const DeviceProblem *C = &W->D;
     const bool keep = suspended && W->vq_jsave != nullptr;  // volley queue: partial sums and counters stay with the wave
     if (W->vq_jsave) {

@@ -131,6 +131,9 @@ struct TardisMcContext {
     // A 1e8 packets of configs[2] -1.2 ... -1.8 %, 2e7 -4 %, 1.25e7 -6 %, uniform levels -4.5 %, configs[1] -1 %; B +3.5 %; aligned runs (2) +2 ... +6 %
     // on the heavy-tailed tables (a trace's first step is shorter: 8 % more steps), -5 % on the uniform ones.
     int sweep_table = -1;
+    // Shell-sorted log (round 6; propagate_wave_kernel<..., SL>): every chunk of the line-visit log holds records of one shell, the estimator passes start with
+    // the partition by bin.  -1 (default): where the kernel has it (the production lane-sweep instantiations, <= 64 shells, partition pipeline); 0 off
+    int log_by_shell = -1;
     DevBuf nt_t;
     bool nt_valid = false;
     unsigned nt_stride = 0;
@@ -180,7 +183,7 @@ struct TardisMcContext {
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
     int log_tail_packets = 8;               // tail split: packets' worth of traces a lane in flight still logs after the supply has run out
     int log_tail_split = 1;                 // plan the epochs so that the last one holds only the drain of the call (see tardis_mc_propagate)
-    int est_accumulate = 1;                 // accumulate kernel of the index pipeline: 1 with block sums (accumulate_blocks_kernel), 0 one add per line visit (accumulate_kernel)
+    int est_accumulate = 1;                 // accumulate kernel: 2 dyadic hierarchy of block sums (accumulate_dyadic_kernel), 1 8-line block sums (accumulate_blocks_kernel), 0 one add per line visit (accumulate_kernel, index pipeline only)
     int est_pipeline = 1;                   // line-estimator passes: 1 two-level partition of the records (estimator_partition.hpp), 0 index sort + gather (estimator_log.hpp)
     DevBuf log_part;                        // est_pipeline 1: the scratch copy of one epoch's records, shared by both buffer sets
     long long log_chunk_records = 0;        // records per chunk of the line-visit log's pool (0: automatic, <= 4096; tests)
@@ -454,8 +457,16 @@ __global__ void __launch_bounds__(256) stream_copy_kernel(double *table, long lo
     const v2d *__restrict__ src = reinterpret_cast<const v2d *>(table);
     v2d *__restrict__ dst = reinterpret_cast<v2d *>(table + half);
     const long long pieces = half / 2, step = (long long)gridDim.x * blockDim.x;
-    for (int it = 0; it < iters; ++it)
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pieces; i += step) dst[i] = src[i];
+    for (int it = 0; it < iters; ++it) {
+        long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * step < pieces; i += 4 * step) {  // four 16-byte pieces in flight per lane
+            const v2d a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + step);
+            const v2d c = __builtin_nontemporal_load(src + i + 2 * step), d = __builtin_nontemporal_load(src + i + 3 * step);
+            __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + step);
+            __builtin_nontemporal_store(c, dst + i + 2 * step); __builtin_nontemporal_store(d, dst + i + 3 * step);
+        }
+        for (; i < pieces; i += step) dst[i] = src[i];
+    }
 }
 
 // ---- real-packet spectrum and filtered luminosities from the resident per-packet outputs
@@ -784,11 +795,12 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
     else if (n == "vpk_wave_min_packets") ctx->vpk_wave_min_packets = std::max<long long>(0, value);
     else if (n == "ls_waves_per_simd") { ctx->ls_waves_per_simd = (value == 3 || value == 4) ? (int)value : 0; ctx->ls_tune.n = -1; }
+    else if (n == "log_by_shell") ctx->log_by_shell = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "sweep_table") ctx->sweep_table = (int)std::max<long long>(-1, std::min<long long>(value, 2));
     else if (n == "vpk_wide_registers") ctx->vpk_wide_registers = (int)std::max<long long>(0, std::min<long long>(value, 2));
     else if (n == "bucket_lines_permille") ctx->bucket_lines_permille = (int)std::max<long long>(50, std::min<long long>(value, 16000));
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
-    else if (n == "est_accumulate") ctx->est_accumulate = value ? 1 : 0;
+    else if (n == "est_accumulate") ctx->est_accumulate = (int)std::max<long long>(0, std::min<long long>(value, 2));
     else if (n == "log_tail_packets") ctx->log_tail_packets = (int)std::max<long long>(0, std::min<long long>(value, 1000));
     else if (n == "log_chunk_records") ctx->log_chunk_records = value <= 0 ? 0 : std::max<long long>(256, std::min<long long>(value, 1 << 20));
     else if (n == "walk_min_active") {  // (-1: never carry a walk over; < -1: the automatic choice again)
@@ -1526,7 +1538,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
         ctx->launches = 0;
         if (wave_kernel) {
             const bool lane_sweep = variant == 3 && !full;  // (the bounds of the lane sweep are those of partial relativity)
-            const size_t wave_lds = lane_sweep ? (vpk ? mc::wave_kernel_lds_bytes<false, true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false, true>(ctx->n_shells))
+            size_t wave_lds = lane_sweep ? (vpk ? mc::wave_kernel_lds_bytes<false, true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false, true>(ctx->n_shells))
                                   : vpk ? (full ? mc::wave_kernel_lds_bytes<true, true>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, true>(ctx->n_shells))
                                         : (full ? mc::wave_kernel_lds_bytes<true, false>(ctx->n_shells) : mc::wave_kernel_lds_bytes<false, false>(ctx->n_shells));
             if (wave_lds > 64 * 1024) return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "n_shells too large for the LDS J/nu_bar accumulator");
@@ -1542,7 +1554,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
 #define TMC_PICKLS2(V_, X_) (trk ? mc::propagate_wave_kernel<false, true, 16, V_, true, X_> : mc::propagate_wave_kernel<false, false, 16, V_, true, X_>)
 #define TMC_PICKLS(V_) (xwalk ? TMC_PICKLS2(V_, true) : TMC_PICKLS2(V_, false))
             // (flag 1048576: the long instantiations, for A/B; the flags that read the kernel's profiling / test counters: those are only compiled into the long ones)
-            const int dbg_counter_flags = 1 | 2 | 4 | 16 | 32 | 16384 | 32768 | 65536 | 131072 | 2097152 | 4194304 | 8388608 | 16777216 | 134217728 | 268435456 | 524288;  // (+ the ablation flags 1 / 2 / 4 / 16777216)
+            const int dbg_counter_flags = mc::WV_DBG_FLAGS;  // (defined next to the kernel's DBG-gated code: propagate_wave.hpp)
             const bool xwalk = (c.line_interaction_type != 0 && !compact_walk) || (ctx->debug_flags & (1048576 | dbg_counter_flags)) != 0;
             // (sweep-worker width of the wave kernel: 8 lanes for sparse line lists, 16 for long ones, like the group kernel; the lane-sweep
             // instantiations only use it in the cross-check walks: one width)
@@ -1550,8 +1562,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             if (lane_sweep) kw = vpk ? TMC_PICKLS(true) : TMC_PICKLS(false);
             else kw = (GW == 16) ? TMC_PICKW(16) : (GW == 4 ? TMC_PICKW(4) : TMC_PICKW(8));
             // v-packets on a grid so fine that the per-shell LDS arrays leave room for at most eight waves per CU (two per SIMD): the
-            // instantiation compiled for two waves per SIMD -- 239 VGPRs, no spills -- costs no occupancy there (only built for the long-list
-            // width G = 16 without the cross-check walks; option vpk_wide_registers 0 keeps the 168-VGPR one)
+            // instantiation compiled for two waves per SIMD -- 239 VGPRs, no spills -- costs no occupancy there (built for the sweep widths G = 16 and
+            // G = 8, without the cross-check walks; option vpk_wide_registers 0 keeps the 168-VGPR one)
             // Measured (profiles/r05_vpk_wide_registers.txt): 3727-3766 vs 4442-4450 ms per 1e7 packets of the configs[4] shape (-16 %).  Option 2 forces
             // it (then eight waves per CU whatever the LDS allows), 0 keeps the 168-VGPR instantiation.
             bool wide = vpk && !lane_sweep && !xwalk && (GW == 16 || GW == 8) &&
@@ -1564,7 +1576,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             bool ls3 = false;
             if (lane_sweep && !vpk && !xwalk) {
                 auto &tn = ctx->ls_tune;
-                if (ctx->ls_waves_per_simd == 3) ls3 = true;
+                // (a call that does not even fill the grid's lanes four times over is nothing but the drain of its longest packets: B, measured -6 % on
+                // 1e5 - 1e6-packet calls of the tardis_example shape, without spending five calls of a 20-iteration run on finding that out)
+                const bool all_drain = ctx->n_packets < 4LL * 64 * 16 * cus;
+                if (ctx->ls_waves_per_simd == 3 || (ctx->ls_waves_per_simd == 0 && all_drain)) ls3 = true;
                 else if (ctx->ls_waves_per_simd == 0 && ctx->pass_cus == 0) {
                     if (tn.n != ctx->n_packets || tn.lines != ctx->n_lines || tn.shells != ctx->n_shells || tn.mode != c.line_interaction_type ||
                         tn.table != ctx->sweep_table) {
@@ -1641,6 +1656,14 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             // est_pipeline 1 (estimator_partition.hpp): the records are grouped by shell, then by bin; needs a shell's bins and all shells
             // to fit the partition kernel's local buckets
             const bool partition = ctx->est_pipeline == 1 && tiles <= mc::PART_LOCAL_BUCKETS && ctx->n_shells <= mc::PART_LOCAL_BUCKETS;
+            // the shell-sorted log: instantiated for the two production lane-sweep kernels (sixteen waves on the interleaved table, twelve on the separate ones)
+            const bool shell_log = lane_sweep && !vpk && !xwalk && !vq && partition && ctx->log_by_shell != 0 && ctx->n_shells <= 64 &&
+                                   ((!ls3 && nt_mode == 1) || (ls3 && nt_mode == 0));
+            if (shell_log) {
+                if (ls3) kw = trk ? mc::propagate_wave_kernel<false, true, 16, false, true, false, 3, 0, true> : mc::propagate_wave_kernel<false, false, 16, false, true, false, 3, 0, true>;
+                else kw = trk ? mc::propagate_wave_kernel<false, true, 16, false, true, false, 4, 1, true> : mc::propagate_wave_kernel<false, false, 16, false, true, false, 4, 1, true>;
+                wave_lds = mc::wave_kernel_lds_bytes<false, false, true, true>(ctx->n_shells);
+            }
             long long log_capacity = ctx->log_capacity;
             if (!ctx->log_capacity_user) {
                 // (fewer, longer epochs are faster -- 25.8 vs 24.5 Mpkt/s at 1e8 packets with 2.5e9 instead of 1.5e9 records per set
@@ -1663,10 +1686,13 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             unsigned region_capacity = 0;  // records per chunk
             unsigned long long n_chunks = 0;
             if (cap > 0) {
-                region_capacity = ctx->log_chunk_records > 0 ? (unsigned)ctx->log_chunk_records : 4096u;
-                while (region_capacity > 256 && (unsigned long long)region_capacity * 4ull * (unsigned long long)waves > cap) region_capacity >>= 1;
+                // (shell-sorted log: a wave holds an open chunk per shell it has logged into -- the pool needs several chunks per wave AND shell; chunks of
+                // 2048 records are what the partition kernel stages at a time)
+                const unsigned long long per_wave = shell_log ? 4ull * (unsigned long long)std::min(ctx->n_shells, 8) : 4ull;
+                region_capacity = ctx->log_chunk_records > 0 ? (unsigned)ctx->log_chunk_records : (shell_log ? 2048u : 4096u);
+                while (region_capacity > 256 && (unsigned long long)region_capacity * per_wave * (unsigned long long)waves > cap) region_capacity >>= 1;
                 region_capacity &= ~1u;  // even: a chunk of 24-byte records then starts on a 16-byte boundary (partition_kernel stages with 16-byte loads)
-                n_chunks = std::max<unsigned long long>(cap / region_capacity, (unsigned long long)waves);
+                n_chunks = std::max<unsigned long long>(cap / region_capacity, (unsigned long long)waves * (shell_log ? (unsigned long long)(ctx->n_shells + 4) : 1ull));
                 if (n_chunks * region_capacity > 0xfffffff0ull) n_chunks = 0xfffffff0ull / region_capacity;
             }
             // (waves take chunks dynamically: every launch can suspend)
@@ -1803,24 +1829,49 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                     unsigned *shell_fill = slice_start + (n_bins + 2);
                     mc::LineVisitRecord *scratch = ctx->log_part.as<mc::LineVisitRecord>();
                     auto bits_of = [](int n) { int b = 0; while ((1 << b) < n) ++b; return b; };
+                    const mc::LineVisitRecord *binned = lg.records;  // what the accumulate kernel reads
+                    if (shell_log) {  // the chunks hold one shell each: straight to the partition by bin, into the scratch copy
+                        hipLaunchKernelGGL(mc::partition_kernel<2>, dim3(cus * 2), dim3(mc::PART_THREADS), 0, es, lg.records, lg.keys, lg.region_count, lg.n_regions,
+                                           lg.region_capacity, (const unsigned *)nullptr, lg.tiles_per_shell, ctx->n_lines, bits_of(mc::PART_LOCAL_BUCKETS), bin_fill, scratch);
+                        binned = scratch;
+                    } else {
                     hipLaunchKernelGGL(mc::partition_shell_fill_kernel, dim3(1), dim3(256), 0, es, bin_start, lg.tiles_per_shell, ctx->n_shells, shell_fill);
                     const int part_blocks = cus * 2;
-                    hipLaunchKernelGGL(mc::partition_kernel<true>, dim3(part_blocks), dim3(mc::PART_THREADS), 0, es, lg.records, lg.keys, lg.region_count,
+                    hipLaunchKernelGGL(mc::partition_kernel<1>, dim3(part_blocks), dim3(mc::PART_THREADS), 0, es, lg.records, lg.keys, lg.region_count,
                                        lg.n_regions, lg.region_capacity, (const unsigned *)nullptr, lg.tiles_per_shell, ctx->n_lines, bits_of(ctx->n_shells),
                                        shell_fill, scratch);
-                    hipLaunchKernelGGL(mc::partition_kernel<false>, dim3(part_blocks), dim3(mc::PART_THREADS), 0, es, scratch, (const unsigned *)nullptr,
+                    hipLaunchKernelGGL(mc::partition_kernel<0>, dim3(part_blocks), dim3(mc::PART_THREADS), 0, es, scratch, (const unsigned *)nullptr,
                                        (const unsigned *)nullptr, 0, 0u, bin_start + n_bins, lg.tiles_per_shell, ctx->n_lines, bits_of(mc::PART_LOCAL_BUCKETS),
                                        bin_fill, lg.records);
+                    }
+                    if (ctx->est_accumulate == 2) {  // the dyadic hierarchy of block sums (accumulate_dyadic_kernel): one workgroup per CU
+                        if (full)
+                            hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<true, true>), dim3(cus), dim3(64 * mc::ACCD_WAVES), 0, es, binned,
+                                               (const unsigned *)nullptr, bin_start, slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                        else
+                            hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<false, true>), dim3(cus), dim3(64 * mc::ACCD_WAVES), 0, es, binned,
+                                               (const unsigned *)nullptr, bin_start, slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                        return hipGetLastError();
+                    }
                     if (full)
-                        hipLaunchKernelGGL((mc::accumulate_blocks_kernel<true, true>), dim3(cus * 2), dim3(64 * mc::ACCB_WAVES), 0, es, lg.records,
+                        hipLaunchKernelGGL((mc::accumulate_blocks_kernel<true, true>), dim3(cus * 2), dim3(64 * mc::ACCB_WAVES), 0, es, binned,
                                            (const unsigned *)nullptr, bin_start, slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
                     else
-                        hipLaunchKernelGGL((mc::accumulate_blocks_kernel<false, true>), dim3(cus * 2), dim3(64 * mc::ACCB_WAVES), 0, es, lg.records,
+                        hipLaunchKernelGGL((mc::accumulate_blocks_kernel<false, true>), dim3(cus * 2), dim3(64 * mc::ACCB_WAVES), 0, es, binned,
                                            (const unsigned *)nullptr, bin_start, slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
                     return hipGetLastError();
                 }
                 hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, es, lg.keys, lg.region_count, lg.n_regions,
                                    lg.region_capacity, n_bins, bin_fill, sorted);
+                if (ctx->est_accumulate == 2) {
+                    if (full)
+                        hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<true, false>), dim3(cus), dim3(64 * mc::ACCD_WAVES), 0, es, lg.records, sorted, bin_start,
+                                           slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                    else
+                        hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<false, false>), dim3(cus), dim3(64 * mc::ACCD_WAVES), 0, es, lg.records, sorted, bin_start,
+                                           slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                    return hipGetLastError();
+                }
                 if (ctx->est_accumulate == 1) {  // one add per aligned block of 8 lines (accumulate_blocks_kernel)
                     const unsigned acc_blocks = (unsigned)(cus * 2);
                     if (full)

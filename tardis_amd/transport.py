@@ -60,7 +60,10 @@ class _PacketProgress:
     INTERVAL = 0.2  # seconds between two polls
 
     def __init__(self, engine, enabled: bool):
-        self.engine, self.enabled, self.interval = engine, bool(enabled), self.INTERVAL
+        import os
+        # (one bar per job: in a multi-process run only rank 0 draws it -- every rank propagates its own shard at the same pace)
+        enabled = bool(enabled) and os.environ.get("RANK", "0") in ("0", "")
+        self.engine, self.enabled, self.interval = engine, enabled, self.INTERVAL
         self.thread = self.stop = self.bar = None
         self.seen = 0
 
@@ -89,6 +92,9 @@ class _PacketProgress:
         if self.enabled:
             import threading
             self.stop = threading.Event()
+            if self.bar and self.seen:  # a second attempt of the same call (the v-packet log was resized): the same bar, from the start
+                self.bar.reset()
+            self.seen = 0
 
             def poll():
                 while not self.stop.wait(self.interval):
@@ -103,9 +109,12 @@ class _PacketProgress:
             self.thread.join()
             if exc[0] is None:
                 self._update(final=True)
-            if self.bar:
-                self.bar.close()
         return False
+
+    def close(self):
+        if self.bar:
+            self.bar.close()
+        self.bar = None
 
 
 def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, time_explosion: float,
@@ -134,10 +143,11 @@ def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, 
     out_nus, out_en = packet_collection.output_nus, packet_collection.output_energies
     in_place = all(isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous for a in (out_nus, out_en))
     vlog_capacity = None
+    progress = _PacketProgress(eng, show_progress_bars)  # (one bar per call, whatever the number of attempts)
     try:
         for _attempt in range(2):
             eng.reset_estimators()
-            with _PacketProgress(eng, show_progress_bars):
+            with progress:
                 eng.propagate()
                 eng.synchronize()
             res = eng.get_results(out_nus if in_place else None, out_en if in_place else None, track_last_interaction=track,
@@ -151,6 +161,7 @@ def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, 
         else:
             raise RuntimeError("v-packet log overflow persisted after resizing")
     finally:
+        progress.close()
         if vlog_capacity is not None:
             eng.set_option("vpacket_log_capacity", 0)  # back to automatic sizing, whichever way the call ended
     if not in_place:
@@ -462,9 +473,13 @@ class MCTransportSolverHIP:
         else:
             eng.set_packets(pc)
         eng.reset_estimators()
-        with _PacketProgress(eng, show_progress_bars):
-            eng.propagate()
-            eng.synchronize()
+        progress = _PacketProgress(eng, show_progress_bars)
+        try:
+            with progress:
+                eng.propagate()
+                eng.synchronize()
+        finally:
+            progress.close()
         res = eng.get_results(track_last_interaction=False, want_line_estimators=False, want_packet_outputs=False)  # small arrays + error check
         if device_packets:
             pc._mark_propagated()

@@ -120,3 +120,78 @@ def test_ballot_ranking_gives_a_permutation_of_the_segment():
         pos = off[keys_all] + rank
         assert np.array_equal(np.sort(pos), np.arange(n))                   # a permutation ...
         assert np.all(np.diff(keys_all[np.argsort(pos)]) >= 0)              # ... that groups the records by bucket
+
+
+# ---- round 6: the dyadic hierarchy of accumulate_dyadic_kernel (csrc/estimator_log.hpp), restated
+TOP = 5
+
+
+def _split(a, n):
+    e = a + n
+    d = int(a ^ e).bit_length() - 1
+    M = (e >> d) << d
+    return M - a, e - M
+
+
+def _nth_bit(v, j):
+    """Position of the j-th lowest set bit of v (the kernel's 32-entry table)."""
+    pos = [b for b in range(5) if (v >> b) & 1]
+    return pos[j]
+
+
+def _dyadic_item(a, up, dn, j):
+    """add_item() of accumulate_dyadic_kernel: (level, first line covered)."""
+    u5, d5 = up & 31, dn & 31
+    pu, mid = bin(u5).count("1"), (up >> 5) + (dn >> 5)
+    if j < pu:
+        level = _nth_bit(u5, j)
+        return level, a + (u5 & ((1 << level) - 1))
+    if j - pu < mid:
+        return TOP, a + u5 + ((j - pu) << TOP)
+    level = _nth_bit(d5, j - pu - mid)
+    return level, a + up + dn - (d5 & ((2 << level) - 1))
+
+
+def test_dyadic_items_tile_a_trace_with_aligned_blocks():
+    """Every line of [a, a + n) is covered exactly once, every block is aligned to its own size (relative to the tile: tiles start on
+    multiples of 2048 lines), nothing outside is touched, and the item count is what the kernel's n_items() says."""
+    worst = 0
+    for a in list(range(0, 130)) + [1023, 1024, 2015, 2047]:
+        for n in list(range(1, 300)) + [511, 512, 513, 1000, 4097]:
+            up, dn = _split(a, n)
+            assert up >= 1 and dn >= 0 and up + dn == n
+            m = bin(up & 31).count("1") + (up >> 5) + (dn >> 5) + bin(dn & 31).count("1")
+            cover = np.zeros(a + n + 64, dtype=np.int32)
+            for j in range(m):
+                level, pos = _dyadic_item(a, up, dn, j)
+                assert 0 <= level <= TOP and pos % (1 << level) == 0, (a, n, j)
+                cover[pos:pos + (1 << level)] += 1
+            assert np.all(cover[a:a + n] == 1) and cover.sum() == n, (a, n)
+            if n <= 255:
+                worst = max(worst, m)
+                assert up < 256 and dn < 256 and a < 2048 or a >= 2048  # (the staged word a | up << 11 | dn << 19 holds them: 11 + 8 + 8 bits)
+    assert worst <= 18  # 64 records of <= 255 lines: <= 18 passes of 64 items (ACCD_PASSES = 20)
+
+
+def test_dyadic_cells_and_flush():
+    """Level l of the accumulators lives at [2 T - (2 T >> l), ...): the levels do not overlap, and a line's flush -- the sum of the six
+    cells above it -- counts every trace over the line exactly once."""
+    T = TILE + APRON
+    cells = 2 * T - ((2 * T) >> (TOP + 1))
+    off = [2 * T - ((2 * T) >> l) for l in range(TOP + 1)]
+    for l in range(TOP + 1):
+        assert off[l] + (T >> l) == (off[l + 1] if l < TOP else cells)
+    rng = np.random.default_rng(3)
+    acc = np.zeros(cells)
+    truth = np.zeros(T)
+    for _ in range(4000):
+        a = int(rng.integers(0, TILE)); n = int(min(rng.geometric(1 / 40.0), T - a))
+        up, dn = _split(a, n)
+        m = bin(up & 31).count("1") + (up >> 5) + (dn >> 5) + bin(dn & 31).count("1")
+        for j in range(m):
+            level, pos = _dyadic_item(a, up, dn, j)
+            acc[off[level] + (pos >> level)] += 1.0
+        truth[a:a + n] += 1.0
+    k = np.arange(T)
+    got = sum(acc[off[l] + (k >> l)] for l in range(TOP + 1))
+    assert np.array_equal(got, truth)

@@ -26,7 +26,7 @@ from tardis_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 EST_RTOL = 1e-11
-MODES = [(1, 1), (0, 1), (0, 0)]  # (est_pipeline, est_accumulate)
+MODES = [(1, 1), (1, 2), (0, 1), (0, 2), (0, 0)]  # (est_pipeline, est_accumulate); accumulate 2 = the dyadic hierarchy of round 6
 
 
 def _oracle(oracle, prob, trace_log=None):
@@ -104,6 +104,28 @@ def test_many_epochs_and_odd_chunks(long_traces, pipeline, accumulate):
     got, launches, _ = _run(prob, pipeline, accumulate, log_capacity=200_000, log_chunk_records=257)
     assert launches >= 2
     _same(got, ref)
+
+
+@pytest.mark.parametrize("accumulate", [1, 2])
+@pytest.mark.parametrize("options", [dict(), dict(log_capacity=200_000, log_chunk_records=257)], ids=["one-launch", "epochs-odd-chunks"])
+def test_two_level_partition_without_the_shell_sorted_log(long_traces, accumulate, options):
+    """Round 6: the production lane-sweep kernels write a shell-sorted log (one open chunk per shell and wave) and the passes start with the
+    partition by bin -- what the tests above run.  `log_by_shell` 0 keeps round 4's form: chunks of mixed shells, partition by shell, then by bin."""
+    prob, ref = long_traces
+    got, launches, variant = _run(prob, 1, accumulate, log_by_shell=0, **options)
+    assert variant == 3
+    _same(got, ref)
+
+
+def test_shell_sorted_log_with_more_shells_than_a_pass_has_lanes_in_one(oracle):
+    """64 shells (the most the shell-sorted log takes), few packets: nearly every record of a pass goes to a shell of its own, chunks close
+    nearly empty, and a pool of a few chunks per wave runs dry again and again (many epochs)."""
+    prob = synthetic.make_problem(seed=21, n_packets=6_000, n_shells=64, n_lines=40_000, line_interaction_type="downbranch")
+    ref, _ = _oracle(oracle, prob)
+    for options in (dict(), dict(log_capacity=60_000, log_chunk_records=256)):
+        got, launches, variant = _run(prob, 1, 2, **options)
+        assert variant == 3
+        _same(got, ref)
 
 
 @pytest.mark.parametrize("full", [False, True])

@@ -146,7 +146,8 @@ def test_the_engine_choosing_between_them_never_changes_a_result(oracle):
     """Default (ls_waves_per_simd 0): the first call of a (packet count, tables) key runs instantiation A untimed, then A, B, A, B timed, from
     the sixth on B if its faster call beat A's faster one by 3 % and A otherwise -- eight calls, eight identical results."""
     from tardis_amd.engine import Engine
-    prob = synthetic.make_problem(seed=9, n_packets=300_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+    # (more packets than four fills of the grid's lanes: below that the engine takes B without timing anything)
+    prob = synthetic.make_problem(seed=9, n_packets=1_200_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
     ref = _oracle_full(oracle, prob)
     with Engine(0) as eng:
         eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)

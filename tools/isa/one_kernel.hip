@@ -23,4 +23,7 @@
 #ifndef K_NT
 #define K_NT 0
 #endif
-template __global__ void mc::propagate_wave_kernel<K_FULL, K_TRACK, K_G, K_VPK, K_LS, K_XWALK, K_WPE, K_NT>(mc::WaveHot, const mc::WaveCold *);
+#ifndef K_SL
+#define K_SL false
+#endif
+template __global__ void mc::propagate_wave_kernel<K_FULL, K_TRACK, K_G, K_VPK, K_LS, K_XWALK, K_WPE, K_NT, K_SL>(mc::WaveHot, const mc::WaveCold *);
