@@ -671,9 +671,9 @@ __device__ __forceinline__ int vp_screen_step(const GroupArgs &P, Draw &&draw, i
 // at the trace's current line (as the separate tables' chunks do); 2: the run is the aligned 128-byte line that holds the current line --
 // a step never straddles two lines, the entries in front of the current line are skipped (the first step of a trace is shorter).
 // SL (shell-sorted log, round 6; n_shells <= 64, no volley queue): a wave keeps one open chunk of the line-visit log PER SHELL (chunk and fill in LDS) and appends
-// a trace's record to the chunk of its shell -- the lanes of a pass that log into the same shell find each other with ballots over the shell's bits, as the
-// partition kernel's lanes do -- so that every chunk of the log holds records of ONE shell and the estimator passes start with the partition by bin: the pass that
-// grouped the log by shell (a full read and write of the log: 21 of the 87 ms of passes per 2e9 records, profiles/r04_estimator_partition.txt) is gone.
+// a trace's record to the chunk of its shell (one LDS atomic on the shell's fill), so that every chunk of the log holds records of ONE shell and the estimator passes
+// start with the partition by bin: the pass that grouped the log by shell (a full read and write of the log: 21 of the 87 ms of passes per 2e9 records,
+// profiles/r04_estimator_partition.txt) is gone.
 template <bool FULL, bool TRACK, int G, bool VPK, bool LS = false, bool XWALK = true, int WPE = (VPK ? 3 : 4), int NT = 0, bool SL = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) propagate_wave_kernel(WaveHot H, const WaveCold *__restrict__ W)
 {
@@ -888,49 +888,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         double *const jb = P.jblue_t, *const ed = P.edot_t;
         // a pass appends at most 64 records: without room for them the wave takes the next chunk of the pool (one atomic per chunk)
         bool log_full = false;
-        // SL: the records this pass will append are known here (the lanes whose swept trace passed at least one line), and so are their shells: every
-        // record gets its slot now -- in the open chunk of its shell; a shell's chunk without room for this pass's records is replaced from the pool -- so
-        // that a wave that finds the pool empty suspends before anything of the pass has happened
-        bool sl_log = false;
-        int sl_chunk = -1;
-        unsigned sl_slot = 0;
-        if (SL && log.region_capacity > 0) {
-            if (state == WS_SWEEP && !(LS && s_active)) {
-                const int info = sh.res_info[lane];
-                const int stop_line = (info & 8) ? L : sh.res_line[lane];
-                sl_log = stop_line - p.next_line_id + (((info & 7) == 3) ? 1 : 0) > 0 && !(DBG && (P.debug_flags & 1));
-            }
-            const unsigned long long have = __ballot(sl_log);
-            if (have) {
-                unsigned long long peers = have;  // the lanes that log into this lane's shell
-#pragma unroll
-                for (int b = 0; b < 6; ++b) {
-                    const bool bit = (p.shell >> b) & 1;
-                    const unsigned long long m = __ballot(sl_log && bit);
-                    peers &= bit ? m : ~m;
+        // SL: lane s looks after shell s's open chunk: one without room for a whole pass (64 records, should every lane log into that shell) is closed and
+        // replaced from the pool -- so a pass never runs out of room half-way, and a wave that finds the pool empty suspends before anything of the pass has
+        // happened.  (Ranking this pass's records per shell up front instead -- ballots over the shell's bits, exact reservations, chunks opened on demand --
+        // was built first and measured: +3 % instructions in every pass, propagation +4 %, which took back all the estimator passes gained;
+        // profiles/r06_shell_sorted_log.txt.)
+        if (SL && log.region_capacity > 0 && __ballot(state != WS_DONE) != 0ull) {
+            bool need = false;
+            if (lane < H.n_shells) need = lds_lchunk[lane] < 0 || lds_lused[lane] + 64u > log.region_capacity;
+            if (__ballot(need)) {  // (once per chunk and shell)
+                bool full = false;
+                if (need) {
+                    if (lds_lchunk[lane] >= 0) glob(log.region_count)[lds_lchunk[lane]] = min(lds_lused[lane], log.region_capacity);
+                    const unsigned c = gatomic_add_u32(log.pool_next, 1u);
+                    full = c >= (unsigned)log.n_regions;
+                    lds_lchunk[lane] = full ? -1 : (int)c;
+                    lds_lused[lane] = 0u;
                 }
-                unsigned used = 0;
-                if (sl_log) { sl_chunk = lds_lchunk[p.shell]; used = lds_lused[p.shell]; }
-                const int leader = sl_log ? __builtin_ctzll(peers) : 0;
-                const unsigned cnt = (unsigned)__popcll(peers);
-                const bool need = sl_log && lane == leader && (sl_chunk < 0 || used + cnt > log.region_capacity);
-                if (__ballot(need)) {  // (once per chunk and shell)
-                    bool full = false;
-                    if (need) {
-                        if (sl_chunk >= 0) glob(log.region_count)[sl_chunk] = used;
-                        const unsigned c = gatomic_add_u32(log.pool_next, 1u);
-                        if (c < (unsigned)log.n_regions) sl_chunk = (int)c; else { sl_chunk = -1; full = true; }
-                        used = 0;
-                        lds_lchunk[p.shell] = sl_chunk; lds_lused[p.shell] = 0u;
-                    }
-                    log_full = __ballot(full) != 0ull && W->save != nullptr;  // the pool is empty: the epoch is over for this wave
-                    sl_chunk = __shfl(sl_chunk, leader); used = (unsigned)__shfl((int)used, leader);
-                }
-                if (!log_full && sl_log) {
-                    sl_slot = used + (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
-                    if (lane == leader) lds_lused[p.shell] = used + cnt;
-                }
-                logged_any = true;
+                log_full = __ballot(full) != 0ull && W->save != nullptr;  // the pool is empty: the epoch is over for this wave
             }
         }
         if (!SL && log.region_capacity > 0 && (log_chunk < 0 || log_used + 64 > log.region_capacity) && __ballot(state != WS_DONE) != 0ull) {
@@ -1004,6 +979,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                 start = p.next_line_id;
                 const int stop_line = (info & 8) ? L : sh.res_line[lane];
                 n_visit = stop_line - start + ((code == 3) ? 1 : 0);
+                // (lane sweeps: the lines a trace examined -- those it passed and, unless the list ran out, the one that stopped it -- are counted here, once
+                // per trace, instead of step by step inside the sweep loop)
+                if (LS) visits += (unsigned long long)(unsigned)(stop_line - start + ((info & 8) ? 0 : 1));
                 if (!(info & 8)) p.next_line_id = stop_line;
                 if (code == 4) err = ERR_MONTECARLO;
                 type = code == 1 ? IT_BOUNDARY : (code == 2 ? IT_ESCATTERING : IT_LINE);
@@ -1014,8 +992,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             if (have) {
                 unsigned my = 0;
                 int my_chunk = log_chunk;
-                if (SL) { my = sl_slot; my_chunk = sl_chunk; }  // (reserved at the top of the pass, in the chunk of the record's shell)
-                else {
+                if (SL) {  // the next slot of the shell's open chunk (an LDS atomic hands the lanes of a pass that share a shell distinct slots)
+                    logged_any = true;
+                    if (n_visit > 0) { my = atomicAdd(&lds_lused[p.shell], 1u); my_chunk = lds_lchunk[p.shell]; }
+                } else {
                     my = log_used + (unsigned)__popcll(have & ((1ull << lane) - 1ull));
                     log_used += (unsigned)__popcll(have);
                     logged_any = true;
@@ -1211,8 +1191,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     const int2 bt = gload(P.blk_tab + nxt_arg);
                     mb0 = bt.x; mb1 = bt.y;
                 } else if (nxt == 3)
-                    emit_nu_walk = NT != 0 ? glob(P.nt_t)[2u * ((unsigned)p.shell * P.nt_stride + (unsigned)emit)]
-                                           : glob(P.nu_line)[(unsigned)emit];  // (the sector the coming sweep starts in)
+                    emit_nu_walk = (NT != 0 && emit < L - 1) ? glob(P.nt_t)[2u * ((unsigned)p.shell * P.nt_stride + (unsigned)emit)]
+                                                             : glob(P.nu_line)[(unsigned)emit];  // (the sector the coming sweep starts in; the interleaved table
+                                                                                                  // holds -inf in the frequency slot of the last line)
             }
             if (in_macro) {  // carried over
                 state = WS_WALK;
@@ -1850,7 +1831,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     // loads find their sectors on the way -- VERDICT r04 "next" 4; profiles/r05_tau_sibling_touch.txt)
                     if (DBG && (H.debug_flags & 524288)) {
                         const unsigned touch = reinterpret_cast<const unsigned *>(pt + min(2 * LS_CHUNK - 1, L - 1 + LS_CHUNK - s_line))[1];
-                        if (touch == 0x7ff00001u) ++visits;  // (never: an optical depth is not that NaN pattern; keeps the load alive)
+                        if (touch == 0x7ff00001u) ++dbg_rounds;  // (never: an optical depth is not that NaN pattern; keeps the load alive)
                     }
                     int adv = 0;  // lines of this chunk the trace has passed
                     const double comov = p.nu * dop;
@@ -1902,21 +1883,38 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                             for (int k = 1; k < CH; ++k)
                                 if (k == k0) { f_nu = nl[k]; f_tau = tl[k]; }
                         }
+                        int kf = alive ? CH : k0;  // first entry of the run that did not pass (the lines passed: kf - k0)
 #pragma unroll
                         for (int k = 0; k < CH; ++k) {
                             if (alive && (NT != 2 || k >= k0)) {
                                 const double X = comov - nl[k];
                                 const double x = s_kp * X;
-                                const double D = s_tau_event - s_tau;
                                 const double tau_n = s_tau + tl[k];
                                 const double sum = tau_n + x;
-                                const bool ok = k - k0 < n_fast && X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
-                                if (ok) { s_tau = tau_n; ++adv; }
-                                else { alive = false; f_nu = nl[k]; f_tau = tl[k]; }
+                                bool ok;
+                                if constexpr (NT != 0) {
+                                    // The lean form of the no-stop proof (round 6).  On the interleaved table (built by the host only for tables without a negative
+                                    // optical depth, with -inf in the frequency slot of the last line of the list and of everything behind it) three of the five
+                                    // tests of the general form below are implied by the other two:
+                                    //   * k < n_fast: the last line and the slack fail X < X_b (X = +inf) and go to the exact evaluation, which does not look at the
+                                    //     frequency of the last line;
+                                    //   * X >= 0 (the reference's "nu difference" error) for k > 0: the list is sorted, X grows along it (first entry of a run: tested);
+                                    //   * x < RN(tau_event - tau_prev) (no electron-scattering stop): with tau_line >= 0, RN(tau_prev + x) <= RN(RN(tau_prev + tau_line) + x)
+                                    //     = sum < tau_event gives tau_prev + x < tau_event exactly, hence x <= RN(tau_event - tau_prev), and x exceeds RN(chi d_trace) by
+                                    //     2^-40 relative (K'): d_trace < RN(RN(tau_event - tau_prev) / chi) = d_continuum still follows.  (sum < tau_event, strict:
+                                    //     with <= the first step would only give tau_prev + x <= tau_event + half an ulp.)
+                                    // 22 instead of 31 instructions per line; tests/test_lane_sweep_bounds.py checks the implication on 2e6 inputs within ulps of every threshold.
+                                    ok = (k > (NT == 2 ? k0 : 0) || X >= 0.0) && X < s_xb && sum < s_tau_event;
+                                } else {
+                                    const double D = s_tau_event - s_tau;
+                                    ok = k - k0 < n_fast && X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
+                                }
+                                if (ok) s_tau = tau_n;
+                                else { alive = false; kf = k; f_nu = nl[k]; f_tau = tl[k]; }
                             }
                         }
+                        adv = kf - k0;
                     }
-                    visits += (unsigned long long)adv;
                     if (!alive) {
                         // that line with the reference's own arithmetic (or the for-else, once the list is exhausted)
                         const double chi = sh.d_cont0[lane], d_bound = sh.d_boundary[lane];
@@ -1924,7 +1922,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         int code;
                         double dist;
                         if (line < L) {
-                            ++visits;
                             code = lane_exact_line(H, line, f_nu, f_tau, s_tau, p.nu, comov, chi, s_tau_event, d_bound, dist);
                             if (!code) { s_tau = s_tau + f_tau; ++adv; }
                         } else {

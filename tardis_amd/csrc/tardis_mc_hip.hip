@@ -132,10 +132,21 @@ struct TardisMcContext {
     // on the heavy-tailed tables (a trace's first step is shorter: 8 % more steps), -5 % on the uniform ones.
     int sweep_table = -1;
     // Shell-sorted log (round 6; propagate_wave_kernel<..., SL>): every chunk of the line-visit log holds records of one shell, the estimator passes start with
-    // the partition by bin.  -1 (default): where the kernel has it (the production lane-sweep instantiations, <= 64 shells, partition pipeline); 0 off
-    int log_by_shell = -1;
+    // the partition by bin.  1 / -1: where the kernel has it (the production lane-sweep instantiations, <= 64 shells, partition pipeline); 0 (default) off.
+    // Measured (profiles/r06_shell_sorted_log.txt): the passes of an epoch of 2e9 records 86.5 -> 64.2 ms as priced -- and the propagation launches +4.3 %
+    // (2773 -> 2891-2904 ms per 1e8 packets) whether the slots come from ballot ranks (+3 % instructions) or from one LDS atomic (+1.5 %): net +0.6 ... +1.3 % on
+    // the headline, -2 ... -3 % only where a call's passes are not overlapped by anything (2e7 packets with log_sets 1; configs[1])
+    int log_by_shell = 0;
+    // Split launches (round 6): from the second epoch of a call on, the propagation grid is launched as TWO kernels -- the first half of the waves at once, on the
+    // engine's stream; the second half on the passes' stream, behind the estimator passes of the previous epoch.  While those passes run, the chip holds eight
+    // propagation waves per CU instead of none (the passes' 1024-thread workgroups need half a CU: they cannot be placed beside sixteen resident waves, and used to
+    // run alone at every epoch boundary: 0.37 s of a 3.1-s step); when they are over the second half follows.  Nothing in the kernel changes: the second launch
+    // gets a WaveCold whose per-wave pointers (MT19937 states, suspended lanes / waves, v-packet scratch) are offset by the first launch's wave count.  Option
+    // epoch_split (default 1).
+    int epoch_split = 1;
+    hipEvent_t ev_split[3] = {nullptr, nullptr, nullptr};  // the first launch's inputs are in place | start / end of the second launch
     DevBuf nt_t;
-    bool nt_valid = false;
+    bool nt_valid = false, nt_negative = false;  // (nt_negative: the table holds a negative / NaN optical depth -- the lean proof of the NT kernels does not apply)
     unsigned nt_stride = 0;
     // (the tuner: calls 0-4 of a key run A untimed, A, B, A, B -- each timed call with the tuner's OWN event pair, recorded only when the call was
     // enqueued completely, so that neither another entry point's use of ev_start / ev_stop nor a failed call can leave a stale or unpaired
@@ -273,15 +284,22 @@ __global__ void transpose_kernel(const double *__restrict__ in, double *__restri
     }
 }
 
-// nt[s * stride + l] = {nu_line[l], tau_t[s][l]} (the interleaved sweep table; entries past a row's L lines and the slack behind the last row: zeros)
+// nt[s * stride + l] = {nu_line[l], tau_t[s][l]} (the interleaved sweep table).  The frequency slot of the LAST line of the list, of the entries past a row's L
+// lines and of the slack behind the last row holds -inf: the lane sweep's lean no-stop proof fails there (X = +inf) and hands the line to the exact evaluation,
+// which never reads the last line's frequency (its distance is MISS_DISTANCE) -- so the sweep needs no per-line test for the end of the list.  `negative` is
+// raised if an optical depth is negative or NaN: the lean proof assumes tau >= 0 (the host then keeps such tables on the separate-table kernels).
 __global__ void __launch_bounds__(256) interleave_kernel(const double *__restrict__ nu_line, const double *__restrict__ tau_t, double2 *__restrict__ nt,
-                                                         long long L, long long S, long long stride, long long total)
+                                                         long long L, long long S, long long stride, long long total, int *negative)
 {
+    bool neg = false;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long s = i / stride, l = i - s * stride;
         const bool in = s < S && l < L;
-        nt[i] = in ? make_double2(nu_line[l], tau_t[s * L + l]) : make_double2(0.0, 0.0);
+        const double tau = in ? tau_t[s * L + l] : 0.0;
+        neg |= !(tau >= 0.0);
+        nt[i] = make_double2((in && l < L - 1) ? nu_line[l] : -__builtin_inf(), tau);
     }
+    if (neg) atomicOr(negative, 1);
 }
 
 // Stores a launch-argument block into device memory.  The value travels in the kernel's argument buffer, which the runtime
@@ -604,6 +622,24 @@ int upload_i32(TardisMcContext *ctx, DevBuf &buf, const int64_t *host, size_t n,
     return TARDIS_MC_OK;
 }
 
+// ---- boundary copies between the caller's (pageable) arrays and HBM: plain hipMemcpy.  (Round 6 measured a pipeline of its own -- four worker threads, each with a
+// stream and two pinned 8-MB buffers -- against it: no gain, 29.7 vs 31.6 ms for the 1.28 GB of per-packet results of a 1e7-packet call, 10-26 vs 9.6 ms for the
+// packet upload; the runtime's own staging already runs at ~40-50 GB/s once the destination pages exist.  What did cost 160 ms of that call was on the Python side:
+// fresh tracker arrays allocated, page-faulted and copied once more into the caller's -- Engine.get_results now writes into the caller's arrays;
+// profiles/r06_boundary.txt.)
+struct CopyJob { void *host; void *dev; size_t bytes; };
+
+hipError_t host_copy(TardisMcContext *ctx, const std::vector<CopyJob> &jobs, bool to_device)
+{
+    (void)ctx;
+    for (const CopyJob &j : jobs) {
+        if (!j.host || !j.dev || !j.bytes) continue;
+        hipError_t e = to_device ? hipMemcpy(j.dev, j.host, j.bytes, hipMemcpyHostToDevice) : hipMemcpy(j.host, j.dev, j.bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 mc::DeviceProblem make_device_problem(TardisMcContext *ctx)
 {
     mc::DeviceProblem P{};
@@ -745,6 +781,7 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     for (hipEvent_t e : ctx->ev_post) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_chunk) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_tune) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_split) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->events_host) (void)hipHostFree(ctx->events_host);
@@ -795,6 +832,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "pass_cus") ctx->pass_cus = (int)std::max<long long>(0, std::min<long long>(value, 16));
     else if (n == "vpk_wave_min_packets") ctx->vpk_wave_min_packets = std::max<long long>(0, value);
     else if (n == "ls_waves_per_simd") { ctx->ls_waves_per_simd = (value == 3 || value == 4) ? (int)value : 0; ctx->ls_tune.n = -1; }
+    else if (n == "epoch_split") ctx->epoch_split = value ? 1 : 0;
     else if (n == "log_by_shell") ctx->log_by_shell = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "sweep_table") ctx->sweep_table = (int)std::max<long long>(-1, std::min<long long>(value, 2));
     else if (n == "vpk_wide_registers") ctx->vpk_wide_registers = (int)std::max<long long>(0, std::min<long long>(value, 2));
@@ -870,13 +908,13 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     // tau [L,S] -> [S][L]
     HIP_TRY(ctx, ctx->staging.ensure(std::max(L, T) * S * sizeof(double)));
     HIP_TRY(ctx, ctx->tau_t.ensure((L * S + 2 * mc::LS_CHUNK) * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->staging.p, o->tau_sobolev, L * S * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, host_copy(ctx, {{(void *)o->tau_sobolev, ctx->staging.p, L * S * sizeof(double)}}, true));
     HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->staging.as<double>(), ctx->tau_t.as<double>(), (long long)L, (long long)S));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // probabilities [T,S] -> [S][T]
     HIP_TRY(ctx, ctx->prob_t.ensure(T * S * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->staging.p, o->transition_probabilities, T * S * sizeof(double), hipMemcpyHostToDevice,
-                                ctx->stream));
+    HIP_TRY(ctx, host_copy(ctx, {{(void *)o->transition_probabilities, ctx->staging.p, T * S * sizeof(double)}}, true));
     HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->staging.as<double>(), ctx->prob_t.as<double>(), (long long)T, (long long)S));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int> tmp;
@@ -1120,13 +1158,15 @@ int tardis_mc_set_packets(TardisMcContext *ctx, const TardisMcPackets *p)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)p->n_packets;
     int rc;
-    if ((rc = upload(ctx, ctx->r0, p->initial_radii, P))) return rc;
-    if ((rc = upload(ctx, ctx->mu0, p->initial_mus, P))) return rc;
-    if ((rc = upload(ctx, ctx->nu0, p->initial_nus, P))) return rc;
-    if ((rc = upload(ctx, ctx->e0, p->initial_energies, P))) return rc;
+    HIP_TRY(ctx, ctx->r0.ensure(P * 8)); HIP_TRY(ctx, ctx->mu0.ensure(P * 8)); HIP_TRY(ctx, ctx->nu0.ensure(P * 8)); HIP_TRY(ctx, ctx->e0.ensure(P * 8));
+    HIP_TRY(ctx, ctx->seeds.ensure(P * 4));
     std::vector<uint32_t> seeds(P);
     for (size_t i = 0; i < P; ++i) seeds[i] = (uint32_t)p->packet_seeds[i];  // np.random.seed(int) -> init_genrand(uint32)
-    if ((rc = upload(ctx, ctx->seeds, seeds.data(), P))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (nothing of an earlier call still reads the packet buffers)
+    HIP_TRY(ctx, host_copy(ctx, {{(void *)p->initial_radii, ctx->r0.p, P * 8}, {(void *)p->initial_mus, ctx->mu0.p, P * 8},
+                                      {(void *)p->initial_nus, ctx->nu0.p, P * 8}, {(void *)p->initial_energies, ctx->e0.p, P * 8},
+                                      {(void *)seeds.data(), ctx->seeds.p, P * 4}}, true));
+    (void)rc;
     HIP_TRY(ctx, ctx->out_nu.ensure(P * sizeof(double)));
     HIP_TRY(ctx, ctx->out_e.ensure(P * sizeof(double)));
     if (ctx->track) {
@@ -1618,12 +1658,21 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                     if (!ctx->nt_valid) {
                         const long long total = (long long)(stride * (unsigned long long)ctx->n_shells) + 32;  // (+ the slack of a step's loads behind the last row)
                         HIP_TRY(ctx, ctx->nt_t.ensure((size_t)total * 16));
+                        HIP_TRY(ctx, ctx->pfx_flag.ensure(sizeof(int)));
+                        HIP_TRY(ctx, hipMemsetAsync(ctx->pfx_flag.p, 0, sizeof(int), ctx->stream));
                         hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 65536)), dim3(256), 0, ctx->stream, ctx->nu_line.as<double>(),
-                                           ctx->tau_t.as<double>(), ctx->nt_t.as<double2>(), (long long)ctx->n_lines, (long long)ctx->n_shells, (long long)stride, total);
+                                           ctx->tau_t.as<double>(), ctx->nt_t.as<double2>(), (long long)ctx->n_lines, (long long)ctx->n_shells, (long long)stride, total,
+                                           ctx->pfx_flag.as<int>());
                         HIP_TRY(ctx, hipGetLastError());
+                        int neg = 0;
+                        HIP_TRY(ctx, hipMemcpyAsync(&neg, ctx->pfx_flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                        ctx->nt_negative = neg != 0;
                         ctx->nt_stride = (unsigned)stride;
                         ctx->nt_valid = true;
                     }
+                }
+                if (ctx->nt_valid && !ctx->nt_negative) {
                     nt_mode = (ctx->sweep_table == 2 && !ls3) ? 2 : 1;
                     P.nt_t = ctx->nt_t.as<double>(); P.nt_stride = ctx->nt_stride;
                     if (ls3) kw = trk ? mc::propagate_wave_kernel<false, true, 16, false, true, false, 3, 1> : mc::propagate_wave_kernel<false, false, 16, false, true, false, 3, 1>;
@@ -1686,13 +1735,14 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             unsigned region_capacity = 0;  // records per chunk
             unsigned long long n_chunks = 0;
             if (cap > 0) {
-                // (shell-sorted log: a wave holds an open chunk per shell it has logged into -- the pool needs several chunks per wave AND shell; chunks of
-                // 2048 records are what the partition kernel stages at a time)
-                const unsigned long long per_wave = shell_log ? 4ull * (unsigned long long)std::min(ctx->n_shells, 8) : 4ull;
+                // (shell-sorted log: a wave holds an open chunk for every shell -- the pool needs a few more chunks per wave than there are shells; chunks of
+                // 2048 records are what the partition kernel stages at a time.  A caller's own log_capacity (tests) is respected: with fewer chunks than that
+                // the waves that find the pool empty suspend at once and the call takes more epochs)
+                const unsigned long long per_wave = shell_log ? (unsigned long long)(ctx->n_shells + 4) : 4ull;
                 region_capacity = ctx->log_chunk_records > 0 ? (unsigned)ctx->log_chunk_records : (shell_log ? 2048u : 4096u);
                 while (region_capacity > 256 && (unsigned long long)region_capacity * per_wave * (unsigned long long)waves > cap) region_capacity >>= 1;
                 region_capacity &= ~1u;  // even: a chunk of 24-byte records then starts on a 16-byte boundary (partition_kernel stages with 16-byte loads)
-                n_chunks = std::max<unsigned long long>(cap / region_capacity, (unsigned long long)waves * (shell_log ? (unsigned long long)(ctx->n_shells + 4) : 1ull));
+                n_chunks = std::max<unsigned long long>(cap / region_capacity, (unsigned long long)waves * ((shell_log && !ctx->log_capacity_user) ? per_wave : 1ull));
                 if (n_chunks * region_capacity > 0xfffffff0ull) n_chunks = 0xfffffff0ull / region_capacity;
             }
             // (waves take chunks dynamically: every launch can suspend)
@@ -1769,8 +1819,10 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             }
             if (vpk) HIP_TRY(ctx, ctx->vp_scratch[0].ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(mc::VpResult)));
             if (vpk && ctx->vp_carry_min_active > 0) HIP_TRY(ctx, ctx->vp_park.ensure((size_t)waves * 64 * sizeof(mc::VpPark)));
-            HIP_TRY(ctx, ctx->wave_cold_dev.ensure(2 * sizeof(mc::WaveCold)));
+            HIP_TRY(ctx, ctx->wave_cold_dev.ensure(4 * sizeof(mc::WaveCold)));  // (per epoch parity: the launch's block and the second launch's of a split epoch)
             ctx->wave_cold_host.resize(2);
+            for (hipEvent_t &e : ctx->ev_split)
+                if (!e) HIP_TRY(ctx, hipEventCreate(&e));
             hipStream_t st = ctx->stream;
             HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
             if (tune_slot >= 0) HIP_TRY(ctx, hipEventRecord(ctx->ev_tune[0], st));
@@ -1921,7 +1973,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 if (tail_plan) {
                     const double bulk = records_est - records_done - tail_records;  // what is left before the tail
                     if (bulk > 0.0 && bulk <= (double)n_chunks * (double)region_capacity)
-                        pool_chunks = std::min<unsigned long long>(n_chunks, std::max<unsigned long long>((unsigned long long)waves,
+                        pool_chunks = std::min<unsigned long long>(n_chunks, std::max<unsigned long long>((unsigned long long)waves * (shell_log ? (unsigned long long)(ctx->n_shells + 4) : 1ull),
                                                                                                            (unsigned long long)(bulk / (double)region_capacity) + 1ull));
                 }
                 lg.n_regions = (int)pool_chunks;
@@ -1950,11 +2002,33 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 wc.vq_jsave = vq ? ctx->vq_jsave.as<double>() : nullptr;
                 wc.log_continue = vq ? 1 : 0;
                 wc.log_gen = log_gen;
-                mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + (epoch & 1);
+                mc::WaveCold *wc_dev = ctx->wave_cold_dev.as<mc::WaveCold>() + 2 * (epoch & 1);
                 HIP_TRY(ctx, store_value(st, wc_dev, wc));
+                // split launch (see epoch_split): the estimator passes of the previous epoch are queued (or running) on the second stream
+                // (not the drain launch of a tail-split call: its lanes are the call's critical path, half of them would start behind the bulk's passes)
+                const bool split = ctx->epoch_split && !vq && !cu_masked && !tail_plan && n_sets == 2 && epoch > 0 && es != st && ctx->post_pending[b ^ 1] && waves >= 8 * cus;
+                const int waves1 = split ? waves / 2 : waves;
+                if (split) HIP_TRY(ctx, hipEventRecord(ctx->ev_split[0], st));  // (pool, counters and argument block of this epoch are in place)
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[2], st));
-                hipLaunchKernelGGL(kw, dim3(waves), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
+                hipLaunchKernelGGL(kw, dim3(waves1), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
                 HIP_TRY(ctx, hipGetLastError());
+                double split_w2 = 0.0;  // share of the grid in the second launch
+                if (split) {
+                    mc::WaveCold wc2 = wc;  // the same epoch for waves [waves1, waves): every per-wave array starts waves1 waves further on
+                    wc2.seeded_states = wc.seeded_states + (size_t)waves1 * 64 * mc::WV_STATE_STRIDE;
+                    if (wc.save) wc2.save = wc.save + (size_t)waves1 * 64;
+                    if (wc.wsave) wc2.wsave = wc.wsave + waves1;
+                    if (wc.vp_scratch) wc2.vp_scratch = wc.vp_scratch + (size_t)waves1 * 64 * mc::VP_ROUND;
+                    if (wc.vp_park) wc2.vp_park = wc.vp_park + (size_t)waves1 * 64;
+                    HIP_TRY(ctx, hipStreamWaitEvent(es, ctx->ev_split[0], 0));
+                    HIP_TRY(ctx, store_value(es, wc_dev + 1, wc2));
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_split[1], es));
+                    hipLaunchKernelGGL(kw, dim3(waves - waves1), dim3(64), wave_lds, es, hot, (const mc::WaveCold *)(wc_dev + 1));
+                    HIP_TRY(ctx, hipGetLastError());
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_split[2], es));
+                    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_split[2], 0));  // (what follows on the engine's stream -- the read-back, the next epoch -- follows both)
+                    split_w2 = (double)(waves - waves1) / (double)waves;
+                }
                 if (vq_on) {  // the v-packets this launch requested (the item count is read on the device: an empty list costs a launch)
                     const size_t geo_lds = (size_t)4 * (size_t)ctx->n_shells * sizeof(double);
                     const int tracer_waves = cus * 4 * ctx->vq_tracer_waves_per_simd;
@@ -2026,6 +2100,11 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chunk[4]));
                 float ms = 0.f;
                 HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_chunk[2], ctx->ev_chunk[3]));
+                if (split_w2 > 0.0) {  // a split epoch counts with the wave-weighted duration of its two launches (= the time a launch of the whole grid stands for)
+                    float ms2 = 0.f;
+                    HIP_TRY(ctx, hipEventElapsedTime(&ms2, ctx->ev_split[1], ctx->ev_split[2]));
+                    ms = (float)((1.0 - split_w2) * (double)ms + split_w2 * (double)ms2);
+                }
                 ctx->sum_prop_ms += ms;
                 ctx->prop_pending = false;
                 if (*ctx->suspended_host == 0) { call_complete = true; break; }
@@ -2260,16 +2339,17 @@ int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *res)
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
     };
     if (ctx->have_packets) {
-        HIP_TRY(ctx, d2h(res->output_nus, ctx->out_nu.p, P * 8));
-        HIP_TRY(ctx, d2h(res->output_energies, ctx->out_e.p, P * 8));
+        std::vector<CopyJob> jobs = {{res->output_nus, ctx->out_nu.p, P * 8}, {res->output_energies, ctx->out_e.p, P * 8}};
         if (ctx->track) {
             double *f[] = {res->li_radius, res->li_nu, res->li_energy, res->li_before_nu, res->li_before_mu,
                            res->li_before_energy, res->li_after_nu, res->li_after_mu, res->li_after_energy};
-            for (int k = 0; k < 9; ++k) HIP_TRY(ctx, d2h(f[k], ctx->li_f64[k].p, P * 8));
+            for (int k = 0; k < 9; ++k) jobs.push_back({f[k], ctx->li_f64[k].p, P * 8});
             int64_t *g[] = {res->li_shell_id, res->li_interaction_type, res->li_line_absorb_id, res->li_line_emit_id,
                             res->li_interactions_count};
-            for (int k = 0; k < 5; ++k) HIP_TRY(ctx, d2h(g[k], ctx->li_i64[k].p, P * 8));
+            for (int k = 0; k < 5; ++k) jobs.push_back({g[k], ctx->li_i64[k].p, P * 8});
         }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the propagation and the tracker unpacking are over)
+        HIP_TRY(ctx, host_copy(ctx, jobs, false));
     }
     HIP_TRY(ctx, d2h(res->j_estimator, base + e.J, S * 8));
     HIP_TRY(ctx, d2h(res->nu_bar_estimator, base + e.nubar, S * 8));
@@ -2278,12 +2358,13 @@ int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *res)
         HIP_TRY(ctx, ctx->staging.ensure(L * S * sizeof(double)));
         if (res->j_blue_estimator) {
             HIP_TRY(ctx, launch_transpose(ctx->stream, base + e.jblue, ctx->staging.as<double>(), (long long)S, (long long)L));
-            HIP_TRY(ctx, d2h(res->j_blue_estimator, ctx->staging.p, L * S * 8));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, host_copy(ctx, {{res->j_blue_estimator, ctx->staging.p, L * S * 8}}, false));
         }
         if (res->edotlu_estimator) {
             HIP_TRY(ctx, launch_transpose(ctx->stream, base + e.edot, ctx->staging.as<double>(), (long long)S, (long long)L));
-            HIP_TRY(ctx, d2h(res->edotlu_estimator, ctx->staging.p, L * S * 8));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, host_copy(ctx, {{res->edotlu_estimator, ctx->staging.p, L * S * 8}}, false));
         }
     }
     unsigned long long cnt[TARDIS_MC_N_COUNTERS] = {0};

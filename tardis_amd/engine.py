@@ -147,11 +147,16 @@ class Engine:
         return int(self._L.tardis_mc_last_variant(self._h))
 
     def get_results(self, output_nus=None, output_energies=None, track_last_interaction=True,
-                    want_line_estimators=True, vpacket_log_capacity=None, want_packet_outputs=True) -> _abi.ResultBuffers:
+                    want_line_estimators=True, vpacket_log_capacity=None, want_packet_outputs=True, trackers=None) -> _abi.ResultBuffers:
         """Copy results out.  Every part is optional: per-packet outputs (`want_packet_outputs`), the last-interaction
         trackers, the [L,S] line estimators -- whatever is not asked for stays on the device (the resident outer-iteration
         path reads the spectrum and the radiation field through packet_spectrum() / radiation_field() instead)."""
-        trackers = st.LastInteractionTrackers(self.n_packets) if track_last_interaction else None
+        # (`trackers`: the caller's own LastInteractionTrackers -- the library writes straight into its arrays instead of into fresh ones that
+        # the caller would then copy: 1.1 GB allocated, touched and copied once more per 1e7 packets otherwise)
+        if not track_last_interaction:
+            trackers = None
+        elif not (isinstance(trackers, st.LastInteractionTrackers) and len(trackers) == self.n_packets):
+            trackers = st.LastInteractionTrackers(self.n_packets)
         cap = 0
         if self._vpk_log:
             cap = int(vpacket_log_capacity if vpacket_log_capacity is not None else self.n_packets * self._n_v * 64)

@@ -151,7 +151,7 @@ def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, 
                 eng.propagate()
                 eng.synchronize()
             res = eng.get_results(out_nus if in_place else None, out_en if in_place else None, track_last_interaction=track,
-                                  vpacket_log_capacity=vlog_capacity)
+                                  vpacket_log_capacity=vlog_capacity, trackers=trackers)
             if res.vpacket_log_count <= len(res.vpacket_nus):
                 break
             # The v-packet log was sized from a guess and overflowed (the device then drops entries): the run is
@@ -168,7 +168,9 @@ def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, 
         packet_collection.output_nus[:] = res.output_nus
         packet_collection.output_energies[:] = res.output_energies
     if track:
-        if isinstance(trackers, st.LastInteractionTrackers):
+        if res.trackers is trackers:
+            pass  # (the library wrote into the caller's arrays)
+        elif isinstance(trackers, st.LastInteractionTrackers):
             for n in st.LastInteractionTrackers.F64_FIELDS + st.LastInteractionTrackers.I64_FIELDS:
                 getattr(trackers, n)[:] = getattr(res.trackers, n)
         else:

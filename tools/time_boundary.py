@@ -36,7 +36,7 @@ for rep in range(3):
     t("reset_estimators", eng.reset_estimators)
     t("propagate + synchronize", lambda: (eng.propagate(), eng.synchronize()))
     trk = t("allocate trackers (host)", st.LastInteractionTrackers, n)
-    res = t("get_results (all)", eng.get_results, pc.output_nus, pc.output_energies, True)
+    res = t("get_results (all)", eng.get_results, pc.output_nus, pc.output_energies, True, trackers=trk)
     print(f"  {'total':34s} {1e3 * (time.perf_counter() - t0):9.2f} ms   device {eng.last_propagate_ms():.2f} ms")
     t("get_results (no trackers)", eng.get_results, pc.output_nus, pc.output_energies, False)
     t("get_results (no trk, no line est)", eng.get_results, pc.output_nus, pc.output_energies, False, False)
