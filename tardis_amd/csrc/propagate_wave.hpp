@@ -1857,13 +1857,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                         for (int k = CH - 1; k >= 0; --k) {
                             const double X = comov - nl[k];
                             const double x = s_kp * X;
-                            const double D = s_tau_event - t[k];
                             const double sum = t[k + 1] + x;
-                            const bool ok = X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
+                            bool ok;
+                            if constexpr (NT != 0) ok = (k > 0 || X >= 0.0) && X < s_xb && sum < s_tau_event;  // the lean proof (see the loop form below)
+                            else {
+                                const double D = s_tau_event - t[k];
+                                ok = X >= 0.0 && X < s_xb && x < D && sum <= s_tau_event;
+                            }
                             fail = fail + fail + (ok ? 0u : 1u);
                         }
-                        // (the last line of the list and everything behind it, and every line of a trace outside mid_range, go to the exact evaluation)
-                        fail |= 1u << (s_fast ? min(max(n_fast, 0), CH) : 0);
+                        // (the last line of the list and everything behind it, and every line of a trace outside mid_range, go to the exact evaluation; on the
+                        // interleaved table the end of the list fails by itself: -inf in its frequency slot)
+                        if constexpr (NT != 0) fail |= s_fast ? (1u << CH) : 1u;
+                        else fail |= 1u << (s_fast ? min(max(n_fast, 0), CH) : 0);
                         adv = __builtin_ctz(fail);
                         alive = adv == CH;
                         double ts = t[0];

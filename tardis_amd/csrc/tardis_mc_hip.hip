@@ -127,9 +127,9 @@ struct TardisMcContext {
     // Interleaved sweep table (round 6): nt_t[shell][line] = {nu_line, tau}, 16 bytes per line, rows on 128-byte boundaries -- the eight 16-byte loads of
     // a lane-sweep step come from one run of 128 bytes instead of two runs of 64 bytes in two tables.  Option sweep_table: 0 the separate tables,
     // 1 runs from the current line, 2 aligned runs (propagate_wave_kernel<..., NT>); built by the first propagate call after set_opacity that uses it.
-    // -1 (default): 1 under the sixteen-wave instantiation, the separate tables under the twelve-wave one -- measured (profiles/r06_sweep_table.txt):
-    // A 1e8 packets of configs[2] -1.2 ... -1.8 %, 2e7 -4 %, 1.25e7 -6 %, uniform levels -4.5 %, configs[1] -1 %; B +3.5 %; aligned runs (2) +2 ... +6 %
-    // on the heavy-tailed tables (a trace's first step is shorter: 8 % more steps), -5 % on the uniform ones.
+    // -1 (default) = 1 -- measured (profiles/r06_sweep_table.txt): sixteen-wave instantiation, 1e8 packets of configs[2] -1.0 ... -1.5 %, 2e7 -4 %, 1.25e7 -6 %,
+    // uniform levels -4.5 ... -6 %, configs[1] -1 ... -3 %; twelve-wave instantiation (with the lean proof) -1.7 ... -4.6 %; aligned runs (2) +2 ... +6 % on the
+    // heavy-tailed tables (a trace's first step is shorter: 8 % more steps), -5 % on the uniform ones.
     int sweep_table = -1;
     // Shell-sorted log (round 6; propagate_wave_kernel<..., SL>): every chunk of the line-visit log holds records of one shell, the estimator passes start with
     // the partition by bin.  1 / -1: where the kernel has it (the production lane-sweep instantiations, <= 64 shells, partition pipeline); 0 (default) off.
@@ -141,9 +141,11 @@ struct TardisMcContext {
     // engine's stream; the second half on the passes' stream, behind the estimator passes of the previous epoch.  While those passes run, the chip holds eight
     // propagation waves per CU instead of none (the passes' 1024-thread workgroups need half a CU: they cannot be placed beside sixteen resident waves, and used to
     // run alone at every epoch boundary: 0.37 s of a 3.1-s step); when they are over the second half follows.  Nothing in the kernel changes: the second launch
-    // gets a WaveCold whose per-wave pointers (MT19937 states, suspended lanes / waves, v-packet scratch) are offset by the first launch's wave count.  Option
-    // epoch_split (default 1).
-    int epoch_split = 1;
+    // gets a WaveCold whose per-wave pointers (MT19937 states, suspended lanes / waves, v-packet scratch) are offset by the first launch's wave count.
+    // MEASURED, and a clear loss (profiles/r06_split_launch.txt): parity-green, but configs[2] at 1e8 packets 3 109 -> 4 107 ms -- the passes beside eight resident
+    // waves per CU take three times as long as alone (their workgroups need 72 KB of CONTIGUOUS LDS and find it on few CUs), the second half of the grid idles
+    // meanwhile.  Option epoch_split, default 0.
+    int epoch_split = 0;
     hipEvent_t ev_split[3] = {nullptr, nullptr, nullptr};  // the first launch's inputs are in place | start / end of the second launch
     DevBuf nt_t;
     bool nt_valid = false, nt_negative = false;  // (nt_negative: the table holds a negative / NaN optical depth -- the lean proof of the NT kernels does not apply)
@@ -194,7 +196,7 @@ struct TardisMcContext {
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
     int log_tail_packets = 8;               // tail split: packets' worth of traces a lane in flight still logs after the supply has run out
     int log_tail_split = 1;                 // plan the epochs so that the last one holds only the drain of the call (see tardis_mc_propagate)
-    int est_accumulate = 1;                 // accumulate kernel: 2 dyadic hierarchy of block sums (accumulate_dyadic_kernel), 1 8-line block sums (accumulate_blocks_kernel), 0 one add per line visit (accumulate_kernel, index pipeline only)
+    int est_accumulate = 2;                 // accumulate kernel: 2 dyadic hierarchy of block sums (accumulate_dyadic_kernel), 1 8-line block sums (accumulate_blocks_kernel), 0 one add per line visit (accumulate_kernel, index pipeline only)
     int est_pipeline = 1;                   // line-estimator passes: 1 two-level partition of the records (estimator_partition.hpp), 0 index sort + gather (estimator_log.hpp)
     DevBuf log_part;                        // est_pipeline 1: the scratch copy of one epoch's records, shared by both buffer sets
     long long log_chunk_records = 0;        // records per chunk of the line-visit log's pool (0: automatic, <= 4096; tests)
@@ -917,13 +919,18 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     HIP_TRY(ctx, host_copy(ctx, {{(void *)o->transition_probabilities, ctx->staging.p, T * S * sizeof(double)}}, true));
     HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->staging.as<double>(), ctx->prob_t.as<double>(), (long long)T, (long long)S));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<int> tmp;
     static const int64_t zero64 = 0;
-    if ((rc = upload_i32(ctx, ctx->line2level, macro ? o->line2macro_level_upper : &zero64, macro ? L : 1, tmp))) return rc;
-    if ((rc = upload_i32(ctx, ctx->block_edge, macro ? o->macro_block_edge_index : &zero64, macro ? E : 1, tmp))) return rc;
-    if ((rc = upload_i32(ctx, ctx->ttype, macro ? o->transition_type : &zero64, macro ? T : 1, tmp))) return rc;
-    if ((rc = upload_i32(ctx, ctx->dest, macro ? o->destination_level_id : &zero64, macro ? T : 1, tmp))) return rc;
-    if ((rc = upload_i32(ctx, ctx->tline, macro ? o->transition_line_id : &zero64, macro ? T : 1, tmp))) return rc;
+    std::vector<int> idx32[5];  // (one staging vector per table: the copies are asynchronous, ONE synchronisation below covers them all)
+    auto up32 = [&](int k, DevBuf &buf, const int64_t *host, size_t n) -> int {
+        idx32[k].resize(n);
+        for (size_t i = 0; i < n; ++i) idx32[k][i] = (int)host[i];
+        return upload(ctx, buf, idx32[k].data(), n);
+    };
+    if ((rc = up32(0, ctx->line2level, macro ? o->line2macro_level_upper : &zero64, macro ? L : 1))) return rc;
+    if ((rc = up32(1, ctx->block_edge, macro ? o->macro_block_edge_index : &zero64, macro ? E : 1))) return rc;
+    if ((rc = up32(2, ctx->ttype, macro ? o->transition_type : &zero64, macro ? T : 1))) return rc;
+    if ((rc = up32(3, ctx->dest, macro ? o->destination_level_id : &zero64, macro ? T : 1))) return rc;
+    if ((rc = up32(4, ctx->tline, macro ? o->transition_line_id : &zero64, macro ? T : 1))) return rc;
     {   // packed macro-atom tables of the cooperative kernel
         std::vector<int> lb(2 * (macro ? L : 1), 0), rec(4 * (macro ? T : 1), 0);
         if (macro) {
@@ -957,8 +964,8 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->cum_t.p, ctx->prob_t.p, T * S * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         ctx->prob_negative = false;
         if (macro && E > 1) {
-            int *flag = nullptr;
-            HIP_TRY(ctx, hipMalloc((void **)&flag, sizeof(int)));
+            HIP_TRY(ctx, ctx->pfx_flag.ensure(sizeof(int)));  // (a flag word the context keeps: no hipMalloc / hipFree per opacity state)
+            int *flag = ctx->pfx_flag.as<int>();
             HIP_TRY(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
             const long long n = (long long)(E - 1) * (long long)S;
             hipLaunchKernelGGL(mc::macro_cumulative_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prob_t.as<double>(),
@@ -967,7 +974,6 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
             hipError_t e1 = hipGetLastError();
             hipError_t e2 = hipMemcpyAsync(&neg, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
             hipError_t e3 = hipStreamSynchronize(ctx->stream);
-            (void)hipFree(flag);
             HIP_TRY(ctx, e1); HIP_TRY(ctx, e2); HIP_TRY(ctx, e3);
             ctx->prob_negative = neg != 0;
         }
@@ -1606,11 +1612,12 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             // G = 8, without the cross-check walks; option vpk_wide_registers 0 keeps the 168-VGPR one)
             // Measured (profiles/r05_vpk_wide_registers.txt): 3727-3766 vs 4442-4450 ms per 1e7 packets of the configs[4] shape (-16 %).  Option 2 forces
             // it (then eight waves per CU whatever the LDS allows), 0 keeps the 168-VGPR instantiation.
-            bool wide = vpk && !lane_sweep && !xwalk && (GW == 16 || GW == 8) &&
+            bool wide = vpk && !xwalk && (lane_sweep || GW == 16 || GW == 8) &&
                         ((ctx->vpk_wide_registers == 1 && wave_waves_per_cu <= 8) || ctx->vpk_wide_registers == 2);
 #define TMC_PICKWIDE(G_) (full ? (trk ? mc::propagate_wave_kernel<true, true, G_, true, false, false, 2> : mc::propagate_wave_kernel<true, false, G_, true, false, false, 2>) \
                                : (trk ? mc::propagate_wave_kernel<false, true, G_, true, false, false, 2> : mc::propagate_wave_kernel<false, false, G_, true, false, false, 2>))
-            if (wide) kw = GW == 16 ? TMC_PICKWIDE(16) : TMC_PICKWIDE(8);
+            if (wide) kw = lane_sweep ? (trk ? mc::propagate_wave_kernel<false, true, 16, true, true, false, 2> : mc::propagate_wave_kernel<false, false, 16, true, true, false, 2>)
+                                      : (GW == 16 ? TMC_PICKWIDE(16) : TMC_PICKWIDE(8));  // (lane sweeps with v-packets: variant 3 under partial relativity)
 #undef TMC_PICKWIDE
             // which lane-sweep instantiation (see ls_waves_per_simd above): forced by the option, or timed on the first calls of this key
             bool ls3 = false;
@@ -1652,7 +1659,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             if (ls3) kw = trk ? mc::propagate_wave_kernel<false, true, 16, false, true, false, 3> : mc::propagate_wave_kernel<false, false, 16, false, true, false, 3>;
             // the interleaved sweep table (option sweep_table; the production lane-sweep instantiations only)
             int nt_mode = 0;
-            if (lane_sweep && !vpk && !xwalk && (ctx->sweep_table > 0 || (ctx->sweep_table < 0 && !ls3))) {
+            if (lane_sweep && !vpk && !xwalk && ctx->sweep_table != 0) {
                 const unsigned long long stride = ((unsigned long long)ctx->n_lines + 7ull) & ~7ull;
                 if (stride * (unsigned long long)ctx->n_shells + 32ull < (1ull << 28)) {
                     if (!ctx->nt_valid) {
@@ -1855,7 +1862,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const bool mostly_hot = ctx->have_hot && 2 * ctx->n_hot_blocks > (long long)ctx->n_levels;
             hot.ls_min_active = (!ctx->ls_min_active_user && mostly_hot) ? 12 : ctx->ls_min_active;
             hot.ls_max_steps = ctx->ls_max_steps;
-            hot.walk_min_active = (!ctx->walk_min_active_user && mostly_hot) ? 12 : ctx->walk_min_active;
+            hot.walk_min_active = (!ctx->walk_min_active_user && mostly_hot) ? 16 : ctx->walk_min_active;  // (12 until round 6; with the leaner sweep 16: -1.2 %, profiles/r06_cutoffs.txt)
             hot.vq_min_active = ctx->vq_min_active;
             hot.line_block = P.line_interaction_type != 0 ? P.line_block : nullptr;
             // binning + accumulation of one epoch's line-visit log (estimator_log.hpp)

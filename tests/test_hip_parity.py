@@ -246,7 +246,10 @@ def test_rccl_allreduce_single_rank(engine, oracle):
     prob = synthetic.make_problem(seed=21, n_packets=20_000, n_shells=10, n_lines=4000, line_interaction_type="macroatom")
     from tardis_amd.engine import Engine
     with Engine(0) as eng:
+        with pytest.raises(RuntimeError):
+            eng.comm_check()  # (no communicator yet: TARDIS_MC_ERR_STATE)
         eng.comm_init(0, 1, Engine.comm_unique_id())
+        assert eng.comm_check() == 1  # the self-check of round 6: the all-reduce of (rank + 1) came back as N (N + 1) / 2, N = 1
         eng.set_geometry(prob.geometry, prob.time_explosion)
         eng.set_opacity(prob.opacity_state)
         eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)

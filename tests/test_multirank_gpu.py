@@ -44,7 +44,10 @@ def test_two_ranks_on_one_gpu_match_a_single_rank(tmp_path):
     line1 = _run([sys.executable, "bench.py", "--gpus", "1", "--packets", str(2 * P), "--dump-estimators", str(one)] + common)
     assert line2["n_gpus"] == 2 and line2["scaling"] == "weak" and line2["config"]["packets_per_gpu"] == P
     assert line2["value"] > 0 and line1["n_gpus"] == 1
-    assert "all-reduce" in line2["config"]["parallelism"] or "sum of estimators" in line2["config"]["parallelism"]
+    # two ranks on ONE device: RCCL refuses, every rank agrees on that, the line says so in both places (rccl_ranks = ranks the all-reduce was
+    # verified to span by the (rank + 1) self-check, 0 = host fall-back); the single-rank line carries the field, too
+    assert line2["rccl_ranks"] == 0 and "host-side sum of estimators" in line2["config"]["parallelism"]
+    assert line1["rccl_ranks"] == 1
     a, b = np.load(two), np.load(one)
     for k in ("j_estimator", "nu_bar_estimator", "j_blue_shell_sums", "edotlu_shell_sums", "j_blue_line_sums"):
         assert_allclose(a[k], b[k], rtol=1e-10, err_msg=k)
@@ -75,7 +78,21 @@ def test_eight_ranks_launch_path_on_one_gpu(tmp_path):
     line1 = _run([sys.executable, "bench.py", "--gpus", "1", "--packets", str(8 * P), "--dump-estimators", str(one)] + common)
     assert line8["n_gpus"] == 8 and line8["config"]["packets_per_gpu"] == P and line8["value"] > 0
     assert "x8" in line8["config"]["parallelism"]
+    assert line8["rccl_ranks"] == 0 and "host-side sum of estimators" in line8["config"]["parallelism"]
     a, b = np.load(eight), np.load(one)
     for k in ("j_estimator", "nu_bar_estimator", "j_blue_shell_sums", "edotlu_shell_sums", "j_blue_line_sums"):
         assert_allclose(a[k], b[k], rtol=1e-10, err_msg=k)
     assert line1["n_gpus"] == 1
+
+
+def test_require_rccl_turns_the_fall_back_into_a_failure():
+    """--require-rccl 1 (the default whenever every rank has a GPU of its own, i.e. without --all-on-device): a job whose communicator does not span its
+    ranks prints NO line and exits with rc 3 -- on an 8-GPU node a silent host fall-back cannot pass for an RCCL measurement."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--packets", "20000", "--all-on-device", "0", "--require-rccl", "1",
+                        "--config", "2", "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--boundary-packets", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "--require-rccl" in r.stderr and "rccl_ranks = 0" in r.stderr

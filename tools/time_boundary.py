@@ -14,6 +14,8 @@ from tardis_amd.engine import Engine  # noqa: E402
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 cfg_no = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 kw = dict(synthetic.BASELINE_CONFIGS[cfg_no]); kw.pop("n_packets")
+if os.environ.get("BOUNDARY_MODE"):  # e.g. macroatom on the configs[0] tables: a tardis_example iteration
+    kw["line_interaction_type"] = os.environ["BOUNDARY_MODE"]
 prob = synthetic.make_problem(seed=1, n_packets=1, level_sizes="heavy" if kw["line_interaction_type"] == "macroatom" else "uniform", **kw)
 pc = synthetic.black_body_packets(n, float(prob.geometry.r_inner[0]), 1.0e4)
 eng = Engine(0)
