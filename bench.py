@@ -280,6 +280,9 @@ def main():
             n_b = args.boundary_packets if args.boundary_packets is not None else min(P, 10_000_000)
             if n_b > 0:
                 out["boundary"] = guarded(boundary_call, prob, eng, n_b, not args.no_tracking)
+                # the drop-in call at the headline's own packet count (16 GB of host arrays: only where the box has the memory to spare)
+                if args.boundary_packets is None and P > n_b and isinstance(out["boundary"], dict) and "error" not in out["boundary"]:
+                    out["boundary"]["full_size"] = guarded(boundary_full_size, prob, eng, P, not args.no_tracking)
     if pg.rank == 0 and n_gpus == 1 and args.config == 3 and args.scaling == "weak" and P >= 8_000_000 and not args.no_extra:
         out["strong_scaling_model"] = guarded(strong_scaling_model, eng, P, radius, value)
     eng.close()  # (frees the line-visit log before the extra legs allocate theirs)
@@ -560,6 +563,34 @@ def cpu_baseline(prob, eng, P: int, radius: float, n_sample: int, single_thread:
         "vpacket_spectrum_rel_l2_gpu_vs_cpu": (spectrum.relative_l2(got.v_packets_energy_hist, ref.v_packets_energy_hist)
                                                if ref.counters["vpackets"] > 0 else None),
     }
+
+
+def boundary_full_size(prob, eng, n: int, track: bool) -> dict:
+    """ONE drop-in call of the workload's own packet count on host arrays (BASELINE configs[2]: 1e8 packets = 3.6 GB in, 1.6 + 11.2 GB out): the PCIe-inclusive
+    time of a whole iteration through the reference's boundary, next to `ms_per_step`.  Skipped where the host cannot hold the arrays twice over."""
+    from tardis_amd import transport
+
+    need = n * (36 + 16 + (112 if track else 0)) + 4 * prob.opacity_state.tau_sobolev.nbytes
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:  # noqa: BLE001
+        avail = 0
+    if avail < 2.5 * need:
+        return {"skipped": f"{need / 1e9:.1f} GB of host arrays against {avail / 1e9:.1f} GB available"}
+    t0 = time.perf_counter()
+    pc = synthetic.black_body_packets(n, float(prob.geometry.r_inner[0]), T_INNER)
+    trackers = st.LastInteractionTrackers(n) if track else None
+    t_host = time.perf_counter() - t0
+    cfg = prob.montecarlo_configuration
+    t0 = time.perf_counter()
+    transport.montecarlo_transport_with_vpackets(pc, prob.geometry, prob.time_explosion, prob.opacity_state, cfg, prob.spectrum_frequency_grid, trackers,
+                                                 cfg.NUMBER_OF_VPACKETS, False, None, engine=eng)
+    dt = time.perf_counter() - t0
+    dev = transport.montecarlo_transport_with_vpackets.last_kernel_ms
+    return {"packets": n, "ms": 1e3 * dt, "device_ms": dev, "packets_per_s": n / dt, "host_array_setup_s": t_host,
+            "note": "one call on host arrays at the headline's packet count (upload, set_opacity, propagate, outputs + last-interaction arrays + [L,S] estimators "
+                    "down); the transfers are not overlapped with the propagation; PCIe-inclusive, not `value`"}
 
 
 def boundary_call(prob, eng, n: int, track: bool) -> dict:

@@ -297,6 +297,13 @@ __device__ __forceinline__ int lane_exact_line(const WaveHot &P, int line, doubl
     return stop_b ? 1 : (stop_e ? 2 : (stop_l ? 3 : (err ? 4 : 0)));
 }
 constexpr int LS_CHUNK = 8;  // lines per lane and step (the line list and the tau table carry this much slack at the end)
+#ifndef TMC_LS_CHUNK_NT
+#define TMC_LS_CHUNK_NT 10
+#endif
+// ... of the sixteen-wave instantiation on the interleaved table (its slack: 32 entries).  Ten: with the lean proof the 128-VGPR budget holds two more lines (14 instead
+// of 10 spilled VGPRs), a 36-line trace is 4.1 instead of 5 dependent steps: propagation launches -2.4 % on configs[2] heavy (2 748 / 2 684 -> 2 652 / 2 651 ms per 1e8
+// packets), nothing either way on the uniform levels, the 1.25e7-packet call and configs[1]; twelve (29 spilled VGPRs): +3 ... +7 % (profiles/r06_lines_per_step.txt)
+constexpr int LS_CHUNK_NT = TMC_LS_CHUNK_NT;
 
 // Running sums of the transition probabilities, block by block (macro_atom.py:87-97: `probability += transition_probabilities[i, shell]`
 // from block_start): one thread per (block, shell) repeats the reference's additions once per opacity state, so that a
@@ -1813,7 +1820,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     const double *__restrict__ pn = H.nu_line + (unsigned)s_line;
                     const double *__restrict__ pt = H.tau_t + (s_row + (unsigned)s_line);
                     // (experiment: twelve lines per step in the 150-VGPR instantiation, option ls_waves_per_simd = 3; the tables carry 16 lines of slack)
-                    constexpr int CH = (WPE == 3 && !VPK) ? 12 : LS_CHUNK;
+                    constexpr int CH = (WPE == 3 && !VPK) ? 12 : ((NT == 1 && WPE == 4) ? LS_CHUNK_NT : LS_CHUNK);
                     double nl[CH], tl[CH];
                     typedef double nt2 __attribute__((ext_vector_type(2)));
                     const unsigned nt_at = s_row + (unsigned)s_line;
