@@ -96,3 +96,32 @@ def test_interleaved_sweep_table_on_the_goldens(oracle, name, table):
         assert np.array_equal(getattr(got.trackers, f), g["trk_" + f]), f
     stride = int(g["line_estimator_stride"])
     assert_allclose(got.j_blue_estimator[::stride], g["j_blue_estimator"], rtol=EST_RTOL, atol=0)
+
+
+def test_a_negative_optical_depth_keeps_the_general_proof(oracle):
+    """The lean no-stop proof of the interleaved-table kernels assumes tau >= 0 (an electron-scattering stop is excluded through the line's own
+    optical depth).  A table with negative entries -- population inversions can produce them -- is detected when the interleaved table is built and
+    such a problem stays on the separate tables with the five-test proof: same results as the oracle, whatever `sweep_table` asks for."""
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=11, n_packets=30_000, n_shells=12, n_lines=20_000, line_interaction_type="macroatom")
+    op = prob.opacity_state
+    tau = op.tau_sobolev.copy()
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, tau.size, 400)
+    tau.reshape(-1)[idx] = -np.abs(tau.reshape(-1)[idx]) * 0.5 - 1e-3   # 400 negative optical depths, some of them large
+    bad = st.OpacityState(op.electron_density, op.t_electrons, op.line_list_nu, tau, op.transition_probabilities, op.line2macro_level_upper,
+                          op.macro_block_edge_index, op.transition_type, op.destination_level_id, op.transition_line_id)
+    ref = oracle.run(prob.packet_collection, prob.geometry, prob.time_explosion, bad, prob.montecarlo_configuration, prob.spectrum_frequency_grid,
+                     math_mode=oracle.MATH_PORTABLE, n_threads=oracle.max_threads())
+    for table in (-1, 1, 2):
+        with Engine(0) as eng:
+            eng.set_option("sweep_table", table)
+            eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(bad)
+            eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+            eng.reset_estimators(); eng.propagate(); eng.synchronize()
+            got = eng.get_results(track_last_interaction=True)
+            assert eng.last_variant() == 3
+        assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies), table
+        for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
+            assert got.counters[k] == ref.counters[k], (table, k)
+        assert_allclose(got.j_estimator, ref.j_estimator, rtol=EST_RTOL)
