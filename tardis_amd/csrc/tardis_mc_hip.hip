@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -614,16 +615,6 @@ int upload(TardisMcContext *ctx, DevBuf &buf, const T *host, size_t n)
     return TARDIS_MC_OK;
 }
 
-int upload_i32(TardisMcContext *ctx, DevBuf &buf, const int64_t *host, size_t n, std::vector<int> &tmp)
-{
-    tmp.resize(n);
-    for (size_t i = 0; i < n; ++i) tmp[i] = (int)host[i];
-    int rc = upload(ctx, buf, tmp.data(), n);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // tmp is reused by the caller
-    return TARDIS_MC_OK;
-}
-
 // ---- boundary copies between the caller's (pageable) arrays and HBM: plain hipMemcpy.  (Round 6 measured a pipeline of its own -- four worker threads, each with a
 // stream and two pinned 8-MB buffers -- against it: no gain, 29.7 vs 31.6 ms for the 1.28 GB of per-packet results of a 1e7-packet call, 10-26 vs 9.6 ms for the
 // packet upload; the runtime's own staging already runs at ~40-50 GB/s once the destination pages exist.  What did cost 160 ms of that call was on the Python side:
@@ -879,6 +870,14 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     if (o->n_lines > 0x7ffffff0LL || o->n_transitions > 0x7ffffff0LL)
         return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "line / transition count exceeds 32-bit device indices");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool tmark_on = getenv("TARDIS_MC_TIME_OPACITY") != nullptr;  // (diagnostic: wall time of the stages of this call on stderr)
+    auto tmark_t0 = std::chrono::steady_clock::now();
+    auto tmark = [&](const char *what) {
+        if (!tmark_on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "set_opacity: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tmark_t0).count());
+        tmark_t0 = now;
+    };
     const size_t L = (size_t)o->n_lines, S = (size_t)o->n_shells, T = (size_t)o->n_transitions;
     const size_t E = (size_t)o->n_macro_block_edges;
     // validate the macro-atom index tables on the host: the device walks them without bounds checks
@@ -902,6 +901,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
                 return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "transition_line_id[%zu] out of range", i);
         }
     }
+    tmark("validate");
     int rc;
     // (slack at the end of the line list and of the tau table: the lane sweep loads whole chunks, propagate_wave.hpp)
     HIP_TRY(ctx, ctx->nu_line.ensure((L + 2 * mc::LS_CHUNK) * sizeof(double)));
@@ -914,11 +914,13 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     HIP_TRY(ctx, host_copy(ctx, {{(void *)o->tau_sobolev, ctx->staging.p, L * S * sizeof(double)}}, true));
     HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->staging.as<double>(), ctx->tau_t.as<double>(), (long long)L, (long long)S));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    tmark("nu, n_e, tau up + transpose");
     // probabilities [T,S] -> [S][T]
     HIP_TRY(ctx, ctx->prob_t.ensure(T * S * sizeof(double)));
     HIP_TRY(ctx, host_copy(ctx, {{(void *)o->transition_probabilities, ctx->staging.p, T * S * sizeof(double)}}, true));
     HIP_TRY(ctx, launch_transpose(ctx->stream, ctx->staging.as<double>(), ctx->prob_t.as<double>(), (long long)T, (long long)S));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    tmark("probabilities up + transpose");
     static const int64_t zero64 = 0;
     std::vector<int> idx32[5];  // (one staging vector per table: the copies are asynchronous, ONE synchronisation below covers them all)
     auto up32 = [&](int k, DevBuf &buf, const int64_t *host, size_t n) -> int {
@@ -931,6 +933,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
     if ((rc = up32(2, ctx->ttype, macro ? o->transition_type : &zero64, macro ? T : 1))) return rc;
     if ((rc = up32(3, ctx->dest, macro ? o->destination_level_id : &zero64, macro ? T : 1))) return rc;
     if ((rc = up32(4, ctx->tline, macro ? o->transition_line_id : &zero64, macro ? T : 1))) return rc;
+    tmark("index tables int32 up");
     {   // packed macro-atom tables of the cooperative kernel
         std::vector<int> lb(2 * (macro ? L : 1), 0), rec(4 * (macro ? T : 1), 0);
         if (macro) {
@@ -959,6 +962,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         if ((rc = upload(ctx, ctx->trans_nu, tnu.data(), tnu.size()))) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    tmark("packed tables lb / rec / tnu");
     {   // running sums of the transition probabilities within their blocks (macro_cumulative_kernel)
         HIP_TRY(ctx, ctx->cum_t.ensure((T * S + 8) * sizeof(double)));  // (+8: the jump search reads eight entries at a time)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->cum_t.p, ctx->prob_t.p, T * S * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -978,6 +982,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
             ctx->prob_negative = neg != 0;
         }
     }
+    tmark("running sums");
     ctx->have_walk_tables = false;
     ctx->have_hot = false;
     ctx->n_hot_blocks = 0;
@@ -1033,7 +1038,9 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
                 }
                 if (ctx->n_hot_blocks > 0) {
                     HIP_TRY(ctx, hipMemcpyAsync(ctx->hot_flag.p, hot.data(), n_levels, hipMemcpyHostToDevice, ctx->stream));
-                    HIP_TRY(ctx, launch_hot(ctx->hot_flag.as<unsigned char>(), nullptr));
+                    hipLaunchKernelGGL(mc::walk_hot_flag_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream, ctx->hot_flag.as<unsigned char>(), nb,
+                                       ctx->hot_sec.as<unsigned>());  // (the destinations of the first pass's records, marked; no second walk over the blocks)
+                    HIP_TRY(ctx, hipGetLastError());
                     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                     ctx->have_hot = true;
                 } else {  // no block qualifies (uniform short blocks): S x levels x 64 B -- 0.5 GB at the configs[4] shape -- are not kept for nothing
@@ -1096,6 +1103,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
             ctx->have_walk_tables = true;
         }
     }
+    tmark("compact walk tables + hot sectors");
     ctx->lines_sorted = true;
     for (size_t i = 0; i < L; ++i)
         if (!(o->line_list_nu[i] > 0.0) || (i > 0 && !(o->line_list_nu[i] <= o->line_list_nu[i - 1]))) { ctx->lines_sorted = false; break; }
@@ -1128,6 +1136,7 @@ int tardis_mc_set_opacity(TardisMcContext *ctx, const TardisMcOpacity *o)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         ctx->bucket_shift = shift; ctx->bucket_n = (int)K; ctx->bucket_kmin = kmin;
     }
+    tmark("sorted check + bucket index");
     if (ctx->have_geometry && (int)S != ctx->n_shells)
         return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "opacity has %zu shells, geometry has %d", S, ctx->n_shells);
     ctx->n_lines = (int)L; ctx->n_trans = (int)T; ctx->n_levels = macro ? (int)E - 1 : 0;

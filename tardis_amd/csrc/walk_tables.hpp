@@ -98,30 +98,47 @@ __global__ void __launch_bounds__(256) walk_hot_kernel(const double *__restrict_
 #pragma unroll
     for (int e = 0; e < HOT_ENTRIES; ++e) { lo[e] = 1; hi[e] = 0; dw[e] = 0; kk[e] = 0; wd[e] = 0; }
     unsigned prev16 = 0;  // floor(cum(k-1) * 65536), saturated
-    for (int k = b0; k < b1; ++k) {
-        const double t = c[k] * 65536.0;
-        const unsigned cur16 = t >= 65535.0 ? 65535u : (t > 0.0 ? (unsigned)t : 0u);
-        const unsigned l = k == b0 ? 0u : prev16 + 1u, h = cur16;
-        prev16 = cur16;
-        const int tt = ttype[k];
-        if (h <= l || tt < -1 || k - b0 >= 65535) continue;
-        unsigned d;
-        if (tt == -1) d = (unsigned)tline[k] | WALK_EMIT;
-        else {
-            const int lvl = dest[k];
-            d = (unsigned)lvl | ((hot_flag && hot_flag[lvl]) ? WALK_HOT_DEST : 0u);
-            if ((unsigned)lvl >= WALK_HOT_DEST) continue;
-        }
-        unsigned w = h - l, nl = l, nh = h, nd = d, nk = (unsigned)(k - b0);
+    // (the block is walked by ONE thread -- up to 18 000 rows: the sums and types of eight rows are requested together, so that a row does not wait for
+    // its own loads, and a row's destination is only read if the row is wide enough to enter the list: set_opacity's share of a tardis_example-sized call
+    // was mostly this loop, profiles/r06_boundary.txt)
+    for (int k0 = b0; k0 < b1; k0 += 8) {
+        double cv[8];
+        int tv[8];
 #pragma unroll
-        for (int e = 0; e < HOT_ENTRIES; ++e)  // insertion into the (descending) list of the widest six
-            if (w > wd[e]) {
-                unsigned t0 = wd[e]; wd[e] = w; w = t0;
-                t0 = lo[e]; lo[e] = nl; nl = t0;
-                t0 = hi[e]; hi[e] = nh; nh = t0;
-                t0 = dw[e]; dw[e] = nd; nd = t0;
-                t0 = kk[e]; kk[e] = nk; nk = t0;
+        for (int q = 0; q < 8; ++q) {
+            const bool in = k0 + q < b1;
+            cv[q] = in ? c[k0 + q] : 0.0;
+            tv[q] = in ? ttype[k0 + q] : -2;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q;
+            if (k >= b1) break;
+            const double t = cv[q] * 65536.0;
+            const unsigned cur16 = t >= 65535.0 ? 65535u : (t > 0.0 ? (unsigned)t : 0u);
+            const unsigned l = k == b0 ? 0u : prev16 + 1u, h = cur16;
+            prev16 = cur16;
+            const int tt = tv[q];
+            if (h <= l || tt < -1 || k - b0 >= 65535) continue;
+            if (h - l <= wd[HOT_ENTRIES - 1]) continue;  // not wider than the narrowest of the six: it would not enter the list
+            unsigned d;
+            if (tt == -1) d = (unsigned)tline[k] | WALK_EMIT;
+            else {
+                const int lvl = dest[k];
+                d = (unsigned)lvl | ((hot_flag && hot_flag[lvl]) ? WALK_HOT_DEST : 0u);
+                if ((unsigned)lvl >= WALK_HOT_DEST) continue;
             }
+            unsigned w = h - l, nl = l, nh = h, nd = d, nk = (unsigned)(k - b0);
+#pragma unroll
+            for (int e = 0; e < HOT_ENTRIES; ++e)  // insertion into the (descending) list of the widest six
+                if (w > wd[e]) {
+                    unsigned t0 = wd[e]; wd[e] = w; w = t0;
+                    t0 = lo[e]; lo[e] = nl; nl = t0;
+                    t0 = hi[e]; hi[e] = nh; nh = t0;
+                    t0 = dw[e]; dw[e] = nd; nd = t0;
+                    t0 = kk[e]; kk[e] = nk; nk = t0;
+                }
+        }
     }
     unsigned total = 0;
 #pragma unroll
@@ -132,6 +149,24 @@ __global__ void __launch_bounds__(256) walk_hot_kernel(const double *__restrict_
     out[2] = make_uint4(dw[2], dw[3], dw[4], dw[5]);
     out[3] = make_uint4(kk[0] | (kk[1] << 16), kk[2] | (kk[3] << 16), kk[4] | (kk[5] << 16), total);
     if (mass) mass[(size_t)s * (size_t)n_blocks + (size_t)b] = total;
+}
+
+// The second of the two passes: the choice of the blocks that get a hot sector is made (hot_flag); the records of the first pass name their
+// destinations by block id -- mark those that are themselves entered through a hot sector.  One thread per (block, shell) touches its 64-byte record
+// (what re-running walk_hot_kernel with the flags produced, without walking the blocks again).
+__global__ void __launch_bounds__(256) walk_hot_flag_kernel(const unsigned char *__restrict__ hot_flag, long long n_records, unsigned *__restrict__ hot_sec)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_records) return;
+    unsigned *rec = hot_sec + (size_t)i * 16;
+    const unsigned lo3[3] = {rec[0], rec[1], rec[2]}, hi3[3] = {rec[3], rec[4], rec[5]};
+#pragma unroll
+    for (int e = 0; e < HOT_ENTRIES; ++e) {
+        const unsigned sh16 = 16u * (unsigned)(e & 1);
+        const unsigned l = (lo3[e >> 1] >> sh16) & 0xffffu, h = (hi3[e >> 1] >> sh16) & 0xffffu;
+        const unsigned d = rec[6 + e];
+        if (h > l && !(d & WALK_EMIT) && hot_flag[d & 0x3fffffffu]) rec[6 + e] = d | WALK_HOT_DEST;  // (an empty entry has lo = 1, hi = 0)
+    }
 }
 
 // packed u16 counting: for the two entries of a dword, +1 in the respective half of `less` where entry < x and of `gt`
