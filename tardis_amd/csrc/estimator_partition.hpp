@@ -19,7 +19,11 @@
 
 namespace mc {
 
-constexpr int PART_RECORDS = 2048;      // records a workgroup stages at a time
+#ifndef TMC_PART_RECORDS
+#define TMC_PART_RECORDS 2048
+#endif
+constexpr int PART_RECORDS = TMC_PART_RECORDS;  // records a workgroup stages at a time (2048: two workgroups per CU; 4096 -- one per CU, twice the run length -- measured
+                                                // in round 6: profiles/r06_partition_staging.txt)
 constexpr int PART_THREADS = 1024;
 constexpr int PART_LOCAL_BUCKETS = 1024;  // buckets a staged segment may span (relative to its first one)
 
@@ -150,10 +154,11 @@ __global__ void __launch_bounds__(PART_THREADS) partition_kernel(const LineVisit
         }
         __syncthreads();
         // ---- sorted position of every record and where that position goes (dst32 takes the place of key16 / rank16: read first)
-        static_assert(PART_RECORDS == 2 * PART_THREADS, "two records per thread");
-        unsigned pos[2], where[2];
+        static_assert(PART_RECORDS % PART_THREADS == 0, "whole records per thread");
+        constexpr int PER_T = PART_RECORDS / PART_THREADS;
+        unsigned pos[PER_T], where[PER_T];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < PER_T; ++q) {
             const unsigned i = tid + q * PART_THREADS;
             if (i < n) {
                 const unsigned k = key16[i], r = rank16[i];
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(PART_THREADS) partition_kernel(const LineVisit
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < PER_T; ++q) {
             const unsigned i = tid + q * PART_THREADS;
             if (i < n) { perm[pos[q]] = (unsigned short)i; dst32[pos[q]] = where[q]; }
         }
