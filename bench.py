@@ -407,12 +407,17 @@ def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, tr
     step_bytes = algorithmic_bytes(counters, "step", screened, crossings)
     step_achieved = step_bytes / (last_ms * 1e-3) / 1e9
     survey = None
+    screened_note = None
+    if screened and crossings:
+        screened_note = ("v-packet term: 52 B per shell crossing the volley workers TRACED (kernel counter, one extra untimed call) -- that count includes crossings "
+                         "re-traced after a wrong roulette prediction and the line-by-line steps of unscreened / undecided items, so `achieved` is an upper estimate "
+                         "of the algorithmic rate of a screened trace, not a pure lower-bound byte model")
     if screened:
         b = algorithmic_bytes(counters, "propagate" if wave else "step", False) / launches
         survey = {"algorithmic_bytes_per_launch": b, "achieved": b / (kernel_ms * 1e-3) / 1e9, "frac": b / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "note": "SURVEY 8(d) byte model incl. 16 B per v-packet line visit -- lines the screening no longer reads; context only"}
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "survey_model_with_vpacket_visits": survey,
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "screened_model_note": screened_note,
             "kernel": f"{dominant} (dominant kernel of a step)", "kernel_ms": kernel_ms,
             "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
             "note": "kernel_ms = mean HIP-event duration of the step's propagation launches (the epochs of one "
