@@ -297,6 +297,9 @@ __device__ __forceinline__ int lane_exact_line(const WaveHot &P, int line, doubl
     return stop_b ? 1 : (stop_e ? 2 : (stop_l ? 3 : (err ? 4 : 0)));
 }
 constexpr int LS_CHUNK = 8;  // lines per lane and step (the line list and the tau table carry this much slack at the end)
+#ifndef TMC_STRAIGHT_A
+#define TMC_STRAIGHT_A 0  // (experiment switch: the straight-line sweep form in the sixteen-wave instantiation, too; profiles/r06_lines_per_step.txt)
+#endif
 #ifndef TMC_LS_CHUNK_NT
 #define TMC_LS_CHUNK_NT 10
 #endif
@@ -1853,7 +1856,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                     const int n_fast = L - 1 - s_line;  // lines of the chunk before the last line of the list
                     bool alive;
                     double f_nu, f_tau;
-                    if constexpr (WPE == 3 && !VPK) {
+                    if constexpr ((WPE == 3 && !VPK) || (TMC_STRAIGHT_A != 0 && WPE == 4 && NT == 1)) {
                         // Straight-line form (the twelve-line instantiation only): the reference's serial sums of the chunk first (t[k] = optical
                         // depth in front of line k), then the four bounds of every line -- independent of each other, no exec masking, no branch
                         // per line -- into one bit per line; the first set bit is the line the loop below would have stopped at (same operands,
