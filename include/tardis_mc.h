@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TARDIS_MC_ABI_VERSION 2  /* 2 (round 6): + tardis_mc_comm_check, microbench 15 */
+#define TARDIS_MC_ABI_VERSION 2  /* 2 (round 6): + tardis_mc_comm_check, tardis_mc_stream_results, tardis_mc_streamed_packets, microbench 15 */
 
 enum {
     TARDIS_MC_OK = 0,
@@ -289,6 +289,16 @@ int tardis_mc_radiation_field(TardisMcContext *ctx, double time_of_simulation, c
 int tardis_mc_formal_integral(TardisMcContext *ctx, double inner_temperature, const double *frequencies, int64_t n_frequencies,
                               const double *att_S_ul, const double *Jred_lu, const double *Jblue_lu, int64_t n_impact_parameters,
                               double *luminosity_densities, double *intensities_nu_p);
+
+/* ---- result streaming (optional).  Registers the caller's per-packet result arrays (output_nus / output_energies and the fourteen li_* arrays of *dst; any may
+ * be NULL; the other fields are ignored) as the destination of the NEXT tardis_mc_propagate: a call of the wave-owner kernel that runs as several launches copies the
+ * results of the packets handed out so far to these arrays at every launch boundary, beside the next launch, and tardis_mc_get_results -- given the SAME pointers --
+ * only copies what is left and the packets that were still in flight when their range was copied.  The arrays must stay valid until tardis_mc_get_results returns.
+ * dst = NULL disarms.  Results are identical with and without (tests/test_boundary_gpu.py). */
+int tardis_mc_stream_results(TardisMcContext *ctx, const TardisMcResult *dst);
+/* What the last tardis_mc_propagate streamed: packets [0, *out_streamed) were copied while the call ran (0: the call did not stream -- one launch, another kernel,
+ * fewer packets than the option `stream_min_packets`), *out_resent of them are sent again by tardis_mc_get_results. */
+int tardis_mc_streamed_packets(TardisMcContext *ctx, int64_t *out_streamed, int64_t *out_resent);
 
 /* ---- one-shot API: the reference boundary in one call ---------------------------------------------- */
 int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const TardisMcGeometry *geometry,

@@ -46,6 +46,8 @@ SYMBOLS = {
     "tardis_mc_packet_spectrum": (_i, [_vp, C.c_double, C.c_double, C.c_double, _vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tardis_mc_radiation_field": (_i, [_vp, C.c_double, _vp, C.c_double, C.c_int, _vp, _vp, _vp]),
     "tardis_mc_formal_integral": (_i, [_vp, C.c_double, _vp, C.c_int64, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
+    "tardis_mc_stream_results": (_i, [_vp, _vp]),
+    "tardis_mc_streamed_packets": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tardis_mc_run": (_i, [_vp] * 6),
     "tardis_mc_comm_get_unique_id": (_i, [_vp]),
     "tardis_mc_comm_init": (_i, [_vp, _i, _i, _vp]),

@@ -177,6 +177,33 @@ struct WaveCold {
     double *vq_jsave;  // [waves][2 * n_shells]: the waves' J / nu_bar partial sums between the launches of a volley-queue call
 };
 
+__global__ void __launch_bounds__(64) late_list_kernel(const LaneSave *__restrict__ save, const WaveSave *__restrict__ wsave, int waves, long long first, long long end,
+                                                       unsigned *__restrict__ late, unsigned *__restrict__ late_count, unsigned capacity)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (w >= waves) return;
+    const WaveSave ws = wsave[w];
+    if (ws.done) return;  // (a finished wave holds nothing; its lanes' records are stale)
+    const LaneSave &v = save[(size_t)w * 64 + lane];
+    // (a packet in front of `first` that is still in flight was put on the list at an earlier boundary)
+    const bool live = v.state != WS_NEED_PACKET && v.state != WS_DONE && (long long)v.pkt >= first && (long long)v.pkt < end;
+    const long long r0 = ws.res_next > first ? ws.res_next : first, r1 = ws.res_end < end ? ws.res_end : end;
+    const int n_res = r1 > r0 ? (int)(r1 - r0) : 0;  // reserved, not started (<= 64: a wave reserves max(32, lanes in need) at a time)
+    const unsigned long long lm = __ballot(live);
+    const unsigned n_live = (unsigned)__popcll(lm);
+    unsigned base = 0;
+    if (lane == 0 && n_live + (unsigned)n_res > 0) base = atomicAdd(late_count, n_live + (unsigned)n_res);
+    base = (unsigned)__shfl((int)base, 0);
+    if (live) {
+        const unsigned pos = base + (unsigned)__popcll(lm & ((1ull << lane) - 1ull));
+        if (pos < capacity) late[pos] = (unsigned)v.pkt;
+    }
+    for (int k = lane; k < n_res; k += 64) {
+        const unsigned pos = base + n_live + (unsigned)k;
+        if (pos < capacity) late[pos] = (unsigned)(r0 + k);
+    }
+}
+
 // One worker slot of a group: the trace it is sweeping (group-uniform values) and this lane's line of the current chunk.
 struct SweepSlot {
     int owner;  // lane (in this wave) of the packet being traced, -1: idle
@@ -350,10 +377,13 @@ struct __attribute__((aligned(16))) TrackerRecord {
 };
 static_assert(sizeof(TrackerRecord) == 64, "TrackerRecord is one 64-byte request");
 
-__global__ void __launch_bounds__(256) tracker_unpack_kernel(DeviceProblem D, long long n)
+// (`first`, `count`: the packet range [first, first + count) -- the whole call, or the part of it whose results are streamed to the host while the
+// propagation is still running; `index` non-null: the packets index[0 .. count) instead, the late finishers of streamed ranges)
+__global__ void __launch_bounds__(256) tracker_unpack_kernel(DeviceProblem D, long long first, long long count, const unsigned *__restrict__ index = nullptr)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const long long i = index ? (long long)index[j] : first + j;
     const double e = D.out_e[i];
     if (e == -99.0) return;  // the packet ended with an error: its tracker fields stay as they were
     const TrackerRecord r = reinterpret_cast<const TrackerRecord *>(D.li_rec)[i];
@@ -367,6 +397,18 @@ __global__ void __launch_bounds__(256) tracker_unpack_kernel(DeviceProblem D, lo
     D.li_shell_id[i] = any ? r.shell : -1; D.li_interaction_type[i] = any ? r.type : -1;
     D.li_line_absorb_id[i] = any ? r.absorb : -1; D.li_line_emit_id[i] = any ? r.emit : -1;
     D.li_interactions_count[i] = any ? r.count : 0;
+}
+
+// ---- result streaming (round 6): the packets that had been handed out but not finished when an epoch ended -- the live lanes of the suspended waves and the
+// packets a wave has reserved and not started -- are the ones whose outputs the host may copy too early while the next epoch runs; their indices are collected
+// here (one atomic per wave) and their results are sent again when the call is over.  One 64-thread workgroup per wave of the propagation grid.
+// (late_list_kernel: below, behind LaneSave / WaveSave.)
+// dst[j] = src[index[j]] (8-byte elements): the late finishers' values of one per-packet array, compacted for the copy to the host
+__global__ void __launch_bounds__(256) gather64_kernel(const unsigned long long *__restrict__ src, const unsigned *__restrict__ index, long long n,
+                                                       unsigned long long *__restrict__ dst)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) dst[j] = src[index[j]];
 }
 
 // What a lane needs to start a packet, prepared by launch_prep_kernel for the whole chunk (one record per packet, 48 bytes): the

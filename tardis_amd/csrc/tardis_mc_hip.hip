@@ -245,6 +245,21 @@ struct TardisMcContext {
     int log_sets = 2;
     int last_variant = -1;  // kernel of the last propagate call (see tardis_mc_last_variant)
     int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
+    // result streaming (tardis_mc_stream_results): the caller's per-packet arrays, what has been copied to them while the call ran, and the packets that were
+    // in flight when their range was copied (their results are sent again by get_results)
+    struct ResultStream {
+        bool armed = false;        // destinations registered for the next propagate
+        bool valid = false;        // the last propagate streamed: [0, upto) + the late list are (about to be) in the caller's arrays
+        void *dst[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        long long upto = 0;        // packets [0, upto) were copied at launch boundaries
+        long long n_late = 0;      // entries of the late list (may hold a packet more than once)
+        unsigned late_capacity = 0;
+    } rs;
+    DevBuf rs_late, rs_late_count, rs_vals;
+    hipStream_t rs_stream = nullptr;
+    hipEvent_t rs_ev = nullptr;
+    unsigned long long *rs_next_host = nullptr;  // pinned: the packet counter after a launch
+    long long rs_min_packets = 1000000;  // a range worth sixteen copies of its own (option stream_min_packets; tests lower it)
     // RCCL
     void *comm = nullptr;
     int rank = 0, world = 1;
@@ -633,6 +648,28 @@ hipError_t host_copy(TardisMcContext *ctx, const std::vector<CopyJob> &jobs, boo
     return hipSuccess;
 }
 
+// the sixteen per-packet result arrays on the device / in a TardisMcResult, in one order: out_nu, out_e, nine tracker doubles, five tracker integers
+void per_packet_device_arrays(TardisMcContext *ctx, void *dev[16])
+{
+    dev[0] = ctx->out_nu.p; dev[1] = ctx->out_e.p;
+    for (int k = 0; k < 9; ++k) dev[2 + k] = ctx->track ? ctx->li_f64[k].p : nullptr;
+    for (int k = 0; k < 5; ++k) dev[11 + k] = ctx->track ? ctx->li_i64[k].p : nullptr;
+}
+void per_packet_host_arrays(const TardisMcResult *r, void *host[16])
+{
+    host[0] = r->output_nus; host[1] = r->output_energies;
+    double *f[] = {r->li_radius, r->li_nu, r->li_energy, r->li_before_nu, r->li_before_mu, r->li_before_energy, r->li_after_nu, r->li_after_mu, r->li_after_energy};
+    for (int k = 0; k < 9; ++k) host[2 + k] = f[k];
+    int64_t *g[] = {r->li_shell_id, r->li_interaction_type, r->li_line_absorb_id, r->li_line_emit_id, r->li_interactions_count};
+    for (int k = 0; k < 5; ++k) host[11 + k] = g[k];
+}
+
+__global__ void __launch_bounds__(256) narrow_seeds_kernel(const long long *__restrict__ in, long long n, uint32_t *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)in[i];
+}
+
 mc::DeviceProblem make_device_problem(TardisMcContext *ctx)
 {
     mc::DeviceProblem P{};
@@ -779,6 +816,10 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->events_host) (void)hipHostFree(ctx->events_host);
     if (ctx->ev_events) (void)hipEventDestroy(ctx->ev_events);
+    ctx->rs_late.release(); ctx->rs_late_count.release(); ctx->rs_vals.release();
+    if (ctx->rs_stream) (void)hipStreamDestroy(ctx->rs_stream);
+    if (ctx->rs_ev) (void)hipEventDestroy(ctx->rs_ev);
+    if (ctx->rs_next_host) (void)hipHostFree(ctx->rs_next_host);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream_progress) (void)hipStreamDestroy(ctx->stream_progress);
     if (ctx->ev_progress_reset) (void)hipEventDestroy(ctx->ev_progress_reset);
@@ -827,6 +868,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "ls_waves_per_simd") { ctx->ls_waves_per_simd = (value == 3 || value == 4) ? (int)value : 0; ctx->ls_tune.n = -1; }
     else if (n == "epoch_split") ctx->epoch_split = value ? 1 : 0;
     else if (n == "log_by_shell") ctx->log_by_shell = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "stream_min_packets") ctx->rs_min_packets = std::max<long long>(64, value);
     else if (n == "sweep_table") ctx->sweep_table = (int)std::max<long long>(-1, std::min<long long>(value, 2));
     else if (n == "vpk_wide_registers") ctx->vpk_wide_registers = (int)std::max<long long>(0, std::min<long long>(value, 2));
     else if (n == "bucket_lines_permille") ctx->bucket_lines_permille = (int)std::max<long long>(50, std::min<long long>(value, 16000));
@@ -1175,12 +1217,17 @@ int tardis_mc_set_packets(TardisMcContext *ctx, const TardisMcPackets *p)
     int rc;
     HIP_TRY(ctx, ctx->r0.ensure(P * 8)); HIP_TRY(ctx, ctx->mu0.ensure(P * 8)); HIP_TRY(ctx, ctx->nu0.ensure(P * 8)); HIP_TRY(ctx, ctx->e0.ensure(P * 8));
     HIP_TRY(ctx, ctx->seeds.ensure(P * 4));
-    std::vector<uint32_t> seeds(P);
-    for (size_t i = 0; i < P; ++i) seeds[i] = (uint32_t)p->packet_seeds[i];  // np.random.seed(int) -> init_genrand(uint32)
+    // The seeds arrive as int64 and the kernels read uint32 (np.random.seed(int) -> init_genrand(uint32)): sent as they are and narrowed on the device.  (A host
+    // vector of P words -- zero-filled, then filled -- cost 100 ms of the 200 ms this call took at 1e8 packets; the extra 4 bytes per packet over the link cost 8.)
+    HIP_TRY(ctx, ctx->staging.ensure(P * 8));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (nothing of an earlier call still reads the packet buffers)
     HIP_TRY(ctx, host_copy(ctx, {{(void *)p->initial_radii, ctx->r0.p, P * 8}, {(void *)p->initial_mus, ctx->mu0.p, P * 8},
                                       {(void *)p->initial_nus, ctx->nu0.p, P * 8}, {(void *)p->initial_energies, ctx->e0.p, P * 8},
-                                      {(void *)seeds.data(), ctx->seeds.p, P * 4}}, true));
+                                      {(void *)p->packet_seeds, ctx->staging.p, P * 8}}, true));
+    if (P > 0) {
+        hipLaunchKernelGGL(narrow_seeds_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, ctx->staging.as<long long>(), (long long)P, ctx->seeds.as<uint32_t>());
+        HIP_TRY(ctx, hipGetLastError());
+    }
     (void)rc;
     HIP_TRY(ctx, ctx->out_nu.ensure(P * sizeof(double)));
     HIP_TRY(ctx, ctx->out_e.ensure(P * sizeof(double)));
@@ -1394,6 +1441,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     if (!ctx->have_geometry || !ctx->have_opacity || !ctx->have_config || !ctx->have_packets)
         return fail(ctx, TARDIS_MC_ERR_STATE, "set_geometry/set_opacity/set_config/set_packets must precede propagate");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool rs_armed = ctx->rs.armed;  // (tardis_mc_stream_results holds for one call)
+    ctx->rs.armed = false; ctx->rs.valid = false; ctx->rs.upto = 0; ctx->rs.n_late = 0;
     const int tune_pending = ctx->ls_tune.pending;  // (the lane-sweep tuner: whether the previous propagate call was one of its timed ones: 2 * instantiation + sample)
     ctx->ls_tune.pending = -1;
     int tune_slot = -1;  // this call is a timed one of the tuner (becomes ls_tune.pending once it has been enqueued completely)
@@ -1961,6 +2010,31 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             };
             ctx->post_pending[0] = ctx->post_pending[1] = false;
             ctx->prop_pending = false;
+            // result streaming: only the plain epoch loop (no volley queue, no CU partition), with the tracker unpacking it needs done per range
+            const bool streaming = rs_armed && !vq && !cu_masked && may_suspend && n >= ctx->rs_min_packets;
+            long long rs_pending_lo = 0, rs_pending_hi = 0;  // a range whose unpacking is queued and whose copy the host still has to issue
+            if (streaming) {
+                ctx->rs.late_capacity = (unsigned)std::min<long long>(n, (long long)waves * 64 * 16);
+                HIP_TRY(ctx, ctx->rs_late.ensure((size_t)ctx->rs.late_capacity * sizeof(unsigned)));
+                HIP_TRY(ctx, ctx->rs_late_count.ensure(sizeof(unsigned)));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->rs_late_count.p, 0, sizeof(unsigned), st));
+                if (!ctx->rs_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->rs_stream, hipStreamNonBlocking));
+                if (!ctx->rs_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->rs_ev, hipEventDisableTiming));
+                if (!ctx->rs_next_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->rs_next_host, sizeof(unsigned long long), hipHostMallocDefault));
+            }
+            auto rs_copy_pending = [&]() -> hipError_t {  // the host's part of a streamed range: sixteen copies into the caller's arrays, beside the running launch
+                if (rs_pending_hi <= rs_pending_lo) return hipSuccess;
+                hipError_t e = hipStreamWaitEvent(ctx->rs_stream, ctx->rs_ev, 0);
+                void *dev[16];
+                per_packet_device_arrays(ctx, dev);
+                const size_t off = (size_t)rs_pending_lo * 8, bytes = (size_t)(rs_pending_hi - rs_pending_lo) * 8;
+                for (int a = 0; a < 16 && e == hipSuccess; ++a)
+                    if (ctx->rs.dst[a] && dev[a]) e = hipMemcpyAsync((char *)ctx->rs.dst[a] + off, (char *)dev[a] + off, bytes, hipMemcpyDeviceToHost, ctx->rs_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->rs_stream);
+                ctx->rs.upto = rs_pending_hi;
+                rs_pending_lo = rs_pending_hi = 0;
+                return e;
+            };
             const int max_epochs = 1 << 20;
             // volley queue: on for the bulk of a call; once a launch requests fewer v-packets than keep the tracer's lanes busy the
             // launches are bound by their longest v-packet, not by work -- the rest of the call (the drain of the longest-lived
@@ -2057,6 +2131,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                     HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host, ctx->suspended_dev.p, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
                     if (vq) HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host + 4, ctx->vq_count.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
                     if (region_capacity > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host + 6, lg.pool_next, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    if (streaming) HIP_TRY(ctx, hipMemcpyAsync(ctx->rs_next_host, ctx->next_packet.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[4], st));
                 }
                 ctx->launches += 1;
@@ -2112,6 +2187,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 ctx->post_pending[b] = true;
                 ctx->prop_pending = true;
                 if (!may_suspend) { call_complete = true; break; }  // (no log: the kernel adds its terms directly and never suspends; the call stays asynchronous)
+                // (result streaming: the range unpacked before this launch is copied to the caller's arrays now, while the launch runs)
+                if (streaming) HIP_TRY(ctx, rs_copy_pending());
                 // is anything suspended?  (the only host synchronisation of a call: once per epoch)
                 HIP_TRY(ctx, hipEventSynchronize(ctx->ev_chunk[4]));
                 float ms = 0.f;
@@ -2126,7 +2203,25 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 if (*ctx->suspended_host == 0) { call_complete = true; break; }
                 records_done += (double)std::min<unsigned long long>((unsigned long long)ctx->suspended_host[6], pool_chunks) * (double)region_capacity;
                 if (ctx->suspended_host[2] > 0) split_armed = false;  // (the drain has been split off: the next launch runs to the end)
+                if (streaming) {
+                    // packets [0, handed) have been handed out; those of them still in flight (suspended lanes, reserved blocks) go on the late list, the range
+                    // [upto, handed) is unpacked now -- in front of the next launch on the same stream -- and copied by the host beside that launch
+                    const long long handed = (long long)std::min<unsigned long long>(*ctx->rs_next_host, (unsigned long long)n);
+                    if (handed - ctx->rs.upto >= ctx->rs_min_packets) {
+                        hipLaunchKernelGGL(mc::late_list_kernel, dim3(waves), dim3(64), 0, st, ctx->lane_save.as<mc::LaneSave>(), ctx->wave_save.as<mc::WaveSave>(), waves, ctx->rs.upto, handed,
+                                           ctx->rs_late.as<unsigned>(), ctx->rs_late_count.as<unsigned>(), ctx->rs.late_capacity);
+                        HIP_TRY(ctx, hipGetLastError());
+                        if (ctx->track) {
+                            const long long cnt = handed - ctx->rs.upto;
+                            hipLaunchKernelGGL(mc::tracker_unpack_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, F, ctx->rs.upto, cnt, (const unsigned *)nullptr);
+                            HIP_TRY(ctx, hipGetLastError());
+                        }
+                        HIP_TRY(ctx, hipEventRecord(ctx->rs_ev, st));
+                        rs_pending_lo = ctx->rs.upto; rs_pending_hi = handed;
+                    }
+                }
             }
+            if (streaming && call_complete) HIP_TRY(ctx, rs_copy_pending());  // (a range queued before the last launch)
             if (!call_complete)  // (packets would be left suspended in lane_save, outputs and estimators silently incomplete)
                 return fail(ctx, TARDIS_MC_ERR_STATE, "propagate: %d launches did not finish the call (waves still suspended)", max_epochs);
             if (cu_masked) {  // both masked streams join the engine's stream
@@ -2140,8 +2235,36 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             }
             ctx->wave_epoch_mode = true;
             ctx->progress_done = true;  // (every packet has been handed out and has ended: the host read "nothing suspended")
-            if (ctx->track && n > 0) {  // the wave kernel's tracker records -> the boundary's arrays
-                hipLaunchKernelGGL(mc::tracker_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, F, n);
+            long long unpack_from = 0;
+            if (streaming && ctx->rs.upto > 0) {
+                // what was streamed: [0, upto) minus the late list.  The list's length is read back here (the call has synchronised with every launch already)
+                unsigned n_late = 0;
+                HIP_TRY(ctx, hipMemcpyAsync(&n_late, ctx->rs_late_count.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (n_late <= ctx->rs.late_capacity) {
+                    ctx->rs.valid = true;
+                    ctx->rs.n_late = n_late;
+                    unpack_from = ctx->rs.upto;
+                    if (n_late > 0) {
+                        if (ctx->track) {
+                            hipLaunchKernelGGL(mc::tracker_unpack_kernel, dim3((n_late + 255) / 256), dim3(256), 0, ctx->stream, F, 0LL, (long long)n_late, ctx->rs_late.as<unsigned>());
+                            HIP_TRY(ctx, hipGetLastError());
+                        }
+                        HIP_TRY(ctx, ctx->rs_vals.ensure((size_t)16 * n_late * 8));
+                        void *dev[16];
+                        per_packet_device_arrays(ctx, dev);
+                        for (int a = 0; a < 16; ++a)
+                            if (ctx->rs.dst[a] && dev[a]) {
+                                hipLaunchKernelGGL(mc::gather64_kernel, dim3((n_late + 255) / 256), dim3(256), 0, ctx->stream, (const unsigned long long *)dev[a],
+                                                   ctx->rs_late.as<unsigned>(), (long long)n_late, ctx->rs_vals.as<unsigned long long>() + (size_t)a * n_late);
+                                HIP_TRY(ctx, hipGetLastError());
+                            }
+                    }
+                }  // (else: the list overflowed -- get_results copies everything)
+            }
+            if (ctx->track && n > unpack_from) {  // the wave kernel's tracker records -> the boundary's arrays
+                hipLaunchKernelGGL(mc::tracker_unpack_kernel, dim3((unsigned)((n - unpack_from + 255) / 256)), dim3(256), 0, ctx->stream, F, unpack_from, n - unpack_from,
+                                   (const unsigned *)nullptr);
                 HIP_TRY(ctx, hipGetLastError());
             }
         } else {
@@ -2355,16 +2478,36 @@ int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *res)
         return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
     };
     if (ctx->have_packets) {
-        std::vector<CopyJob> jobs = {{res->output_nus, ctx->out_nu.p, P * 8}, {res->output_energies, ctx->out_e.p, P * 8}};
-        if (ctx->track) {
-            double *f[] = {res->li_radius, res->li_nu, res->li_energy, res->li_before_nu, res->li_before_mu,
-                           res->li_before_energy, res->li_after_nu, res->li_after_mu, res->li_after_energy};
-            for (int k = 0; k < 9; ++k) jobs.push_back({f[k], ctx->li_f64[k].p, P * 8});
-            int64_t *g[] = {res->li_shell_id, res->li_interaction_type, res->li_line_absorb_id, res->li_line_emit_id,
-                            res->li_interactions_count};
-            for (int k = 0; k < 5; ++k) jobs.push_back({g[k], ctx->li_i64[k].p, P * 8});
+        // (arrays a streaming propagate has been filling, tardis_mc_stream_results: only what has not been sent yet)
+        void *dev[16], *host[16];
+        per_packet_device_arrays(ctx, dev);
+        per_packet_host_arrays(res, host);
+        std::vector<CopyJob> jobs;
+        bool patch[16];
+        for (int a = 0; a < 16; ++a) {
+            patch[a] = false;
+            if (!host[a] || !dev[a]) continue;
+            if (ctx->rs.valid && host[a] == ctx->rs.dst[a]) {
+                patch[a] = ctx->rs.n_late > 0;
+                const size_t off = (size_t)ctx->rs.upto * 8;
+                if (P * 8 > off) jobs.push_back({(char *)host[a] + off, (char *)dev[a] + off, P * 8 - off});
+            } else {
+                jobs.push_back({host[a], dev[a], P * 8});
+            }
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the propagation and the tracker unpacking are over)
+        if (ctx->rs.valid && ctx->rs.n_late > 0) {  // the packets that were in flight when their range was sent
+            const size_t m = (size_t)ctx->rs.n_late;
+            std::vector<unsigned> idx(m);
+            std::vector<unsigned long long> vals(m);
+            HIP_TRY(ctx, hipMemcpy(idx.data(), ctx->rs_late.p, m * sizeof(unsigned), hipMemcpyDeviceToHost));
+            for (int a = 0; a < 16; ++a) {
+                if (!patch[a]) continue;
+                HIP_TRY(ctx, hipMemcpy(vals.data(), ctx->rs_vals.as<unsigned long long>() + (size_t)a * m, m * 8, hipMemcpyDeviceToHost));
+                unsigned long long *out = (unsigned long long *)host[a];
+                for (size_t j = 0; j < m; ++j) out[idx[j]] = vals[j];
+            }
+        }
         HIP_TRY(ctx, host_copy(ctx, jobs, false));
     }
     HIP_TRY(ctx, d2h(res->j_estimator, base + e.J, S * 8));
@@ -2431,6 +2574,24 @@ int tardis_mc_get_results(TardisMcContext *ctx, TardisMcResult *res)
         }
     }
     return res->error_code;
+}
+
+int tardis_mc_stream_results(TardisMcContext *ctx, const TardisMcResult *dst)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    ctx->rs.armed = false;
+    if (!dst) return TARDIS_MC_OK;
+    per_packet_host_arrays(dst, ctx->rs.dst);
+    ctx->rs.armed = true;
+    return TARDIS_MC_OK;
+}
+
+int tardis_mc_streamed_packets(TardisMcContext *ctx, int64_t *out_streamed, int64_t *out_resent)
+{
+    if (!ctx) return TARDIS_MC_ERR_INVALID_ARGUMENT;
+    if (out_streamed) *out_streamed = ctx->rs.valid ? ctx->rs.upto : 0;
+    if (out_resent) *out_resent = ctx->rs.valid ? ctx->rs.n_late : 0;
+    return TARDIS_MC_OK;
 }
 
 int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const TardisMcGeometry *geometry,

@@ -166,6 +166,27 @@ class Engine:
         self._check(rc, "get_results", int(res.struct.first_error_packet))
         return res
 
+    def stream_results(self, output_nus=None, output_energies=None, trackers=None) -> None:
+        """Register the host arrays the NEXT propagate call may fill while it runs (`tardis_mc_stream_results`): a long call is several
+        launches, and the per-packet results of the packets a launch has finished are copied beside the following launch instead of
+        after the last one.  get_results() on the same arrays then sends only what is missing; on other arrays it copies everything.
+        No arguments: disarm."""
+        if output_nus is None and output_energies is None and trackers is None:
+            self._stream_keep = None
+            self._check(self._L.tardis_mc_stream_results(self._h, None), "stream_results")
+            return
+        if isinstance(trackers, st.LastInteractionTrackers) and len(trackers) != self.n_packets:
+            raise ValueError("trackers must hold n_packets entries")
+        res = _abi.ResultBuffers(self.n_packets, 0, 0, 0, output_nus, output_energies, trackers, 0, False, output_nus is not None)
+        self._stream_keep = res  # (the arrays stay alive until the call that fills them is over)
+        self._check(self._L.tardis_mc_stream_results(self._h, res.ref()), "stream_results")
+
+    def streamed_packets(self) -> tuple[int, int]:
+        """(packets whose results the last propagate call copied out while it ran, how many of them get_results sends again)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._L.tardis_mc_streamed_packets(self._h, C.byref(a), C.byref(b)), "streamed_packets")
+        return int(a.value), int(b.value)
+
     def run(self, packet_collection, geometry, time_explosion, opacity_state, montecarlo_configuration, spectrum_frequency_grid,
             number_of_vpackets=None, track_last_interaction=True, vpacket_log_capacity=None) -> _abi.ResultBuffers:
         """The one-shot form of the boundary, `tardis_mc_run` (include/tardis_mc.h): geometry, opacity, configuration and packets in,

@@ -147,6 +147,8 @@ def montecarlo_transport_with_vpackets(packet_collection, geometry_state_numba, 
     try:
         for _attempt in range(2):
             eng.reset_estimators()
+            if in_place and _attempt == 0:  # (the caller's arrays are filled while the call runs, launch by launch)
+                eng.stream_results(out_nus, out_en, trackers if isinstance(trackers, st.LastInteractionTrackers) and len(trackers) == eng.n_packets else None)
             with progress:
                 eng.propagate()
                 eng.synchronize()

@@ -236,3 +236,100 @@ def test_show_progress_bars_follows_the_running_call(monkeypatch):
     values = [v for v, _ in seen]
     assert values and values == sorted(values) and 0 <= values[0] and values[-1] == pc.number_of_packets and seen[-1][1]
     assert np.array_equal(pc.output_nus, quiet_nus) and np.array_equal(pc.output_energies, quiet_en)
+
+
+# ---- result streaming (round 6; include/tardis_mc.h: tardis_mc_stream_results) ------------------------------------------------------------
+def _engine_run(prob, n_track, stream, **options):
+    """One call on the engine the way the wrapper makes it; `stream`: the caller's arrays are registered before propagate."""
+    from tardis_amd.engine import Engine
+    P = prob.packet_collection.initial_nus.size
+    out_nu, out_en = np.full(P, -7.0), np.full(P, -7.0)
+    trackers = st.LastInteractionTrackers(P) if n_track else None
+    with Engine(0) as eng:
+        for k, v in options.items():
+            eng.set_option(k, v)
+        eng.set_option("track_last_interaction", int(n_track))
+        eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+        eng.reset_estimators()
+        if stream:
+            eng.stream_results(out_nu, out_en, trackers)
+        eng.propagate(); eng.synchronize()
+        res = eng.get_results(out_nu, out_en, track_last_interaction=bool(n_track), trackers=trackers)
+        assert res.output_nus is out_nu
+        return res, eng.streamed_packets(), eng.last_kernel_times()["launches"]
+
+
+@pytest.mark.parametrize("track", [True, False], ids=["trackers", "outputs-only"])
+@pytest.mark.parametrize("n_packets,capacity", [(1_500_000, 1 << 22), (150_000, 1 << 19)], ids=["ranges", "all-in-flight"])
+def test_streamed_results_are_the_results(n_packets, capacity, track):
+    """A call that runs as several launches copies the results of the packets handed out so far into the caller's arrays beside the next launch;
+    packets that were in flight when their range went out are sent again by get_results.  Same bits in all sixteen arrays as the copy at the end --
+    with more packets than the device holds lanes (ranges of finished packets + a late list) and with fewer (everything is in flight at the first
+    boundary: the whole result is 'late')."""
+    from tardis_amd import synthetic
+    prob = synthetic.make_problem(seed=31, n_packets=n_packets, n_shells=20, n_lines=30_000, line_interaction_type="macroatom")
+    opts = dict(log_capacity=capacity, stream_min_packets=4096)
+    ref, (s0, _), launches0 = _engine_run(prob, track, False, **opts)
+    got, (streamed, resent), launches = _engine_run(prob, track, True, **opts)
+    assert s0 == 0 and launches0 >= 3 and launches >= 3
+    assert streamed >= 4096 and 0 < resent
+    if n_packets > 1_000_000:
+        assert streamed > 1_000_000  # (resent counts every boundary's in-flight packets: many launches here)
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    assert not np.any(got.output_nus == -7.0)
+    if track:
+        for f in st.LastInteractionTrackers.I64_FIELDS:
+            assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f)), f
+        for f in st.LastInteractionTrackers.F64_FIELDS:
+            assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f), equal_nan=True), f
+    assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+    assert got.counters == ref.counters
+
+
+def test_streaming_is_for_one_call_and_for_the_registered_arrays():
+    """Registered arrays serve the next propagate only; get_results on OTHER arrays after a streamed call copies everything; a late list that overflows
+    (capacity forced down through the packet count it is sized from is not reachable here, so: the arming is simply dropped by the next call)."""
+    from tardis_amd import synthetic
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=32, n_packets=600_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+    P = 600_000
+    a_nu, a_en = np.full(P, -7.0), np.full(P, -7.0)
+    with Engine(0) as eng:
+        eng.set_option("log_capacity", 1 << 21); eng.set_option("stream_min_packets", 4096); eng.set_option("track_last_interaction", 0)
+        eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+        eng.reset_estimators(); eng.stream_results(a_nu, a_en, None)
+        eng.propagate(); eng.synchronize()
+        assert eng.streamed_packets()[0] > 0
+        other = eng.get_results(track_last_interaction=False)           # fresh arrays: a full copy
+        mine = eng.get_results(a_nu, a_en, track_last_interaction=False)  # the registered ones: the remainder + the late list
+        assert np.array_equal(other.output_nus, mine.output_nus) and np.array_equal(other.output_energies, mine.output_energies)
+        assert not np.any(other.output_nus == -7.0)
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()      # not armed any more
+        assert eng.streamed_packets() == (0, 0)
+        again = eng.get_results(track_last_interaction=False)
+        assert np.array_equal(again.output_nus, mine.output_nus)
+
+
+def test_the_wrapper_streams_into_the_callers_arrays():
+    """montecarlo_transport_with_vpackets registers packet_collection.output_* and the trackers itself (in-place outputs of the reference:
+    montecarlo_main_loop writes them packet by packet, base.py:168-173)."""
+    from tardis_amd import synthetic
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=33, n_packets=800_000, n_shells=20, n_lines=30_000, line_interaction_type="macroatom")
+    cfg = prob.montecarlo_configuration
+    outs = []
+    for min_packets in (4096, 1 << 40):  # streamed | not
+        pc = prob.packet_collection
+        pc.output_nus[:] = -7.0; pc.output_energies[:] = -7.0
+        trk = st.LastInteractionTrackers(pc.initial_nus.size)
+        with Engine(0) as eng:
+            eng.set_option("log_capacity", 1 << 21); eng.set_option("stream_min_packets", min_packets)
+            transport.montecarlo_transport_with_vpackets(pc, prob.geometry, prob.time_explosion, prob.opacity_state, cfg, prob.spectrum_frequency_grid,
+                                                         trk, 0, False, None, engine=eng)
+            assert (eng.streamed_packets()[0] > 0) == (min_packets == 4096)
+        outs.append((pc.output_nus.copy(), pc.output_energies.copy(), trk))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for f in st.LastInteractionTrackers.I64_FIELDS + st.LastInteractionTrackers.F64_FIELDS:
+        assert np.array_equal(getattr(outs[0][2], f), getattr(outs[1][2], f), equal_nan=True), f

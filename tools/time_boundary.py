@@ -1,5 +1,5 @@
 """Where the host / PCIe time of one drop-in call goes (GPU box): the stages of transport.montecarlo_transport_with_vpackets timed one by one
-on host arrays.   python tools/time_boundary.py [packets] [config: 2 | 3]"""
+on host arrays.   python tools/time_boundary.py [packets] [config: 2 | 3]   (STREAM=1: with result streaming)"""
 import os
 import sys
 import time
@@ -19,6 +19,7 @@ if os.environ.get("BOUNDARY_MODE"):  # e.g. macroatom on the configs[0] tables: 
 prob = synthetic.make_problem(seed=1, n_packets=1, level_sizes="heavy" if kw["line_interaction_type"] == "macroatom" else "uniform", **kw)
 pc = synthetic.black_body_packets(n, float(prob.geometry.r_inner[0]), 1.0e4)
 eng = Engine(0)
+STREAM = bool(int(os.environ.get("STREAM", "0")))
 
 
 def t(label, f, *a, **k):
@@ -36,8 +37,15 @@ for rep in range(3):
     eng.set_option("track_last_interaction", 1)
     t("set_packets", eng.set_packets, pc)
     t("reset_estimators", eng.reset_estimators)
+    if STREAM:  # the caller's arrays registered before the call (what transport.montecarlo_transport_with_vpackets does): filled launch by launch
+        trk = t("allocate trackers (host)", st.LastInteractionTrackers, n)
+        t("stream_results", eng.stream_results, pc.output_nus, pc.output_energies, trk)
     t("propagate + synchronize", lambda: (eng.propagate(), eng.synchronize()))
-    trk = t("allocate trackers (host)", st.LastInteractionTrackers, n)
+    print("  kernel times", eng.last_kernel_times(), " estimator passes", eng.last_estimator_ms() if hasattr(eng, "last_estimator_ms") else None)
+    if STREAM:
+        print("  streamed / resent packets", eng.streamed_packets(), " launches", eng.last_kernel_times()["launches"])
+    else:
+        trk = t("allocate trackers (host)", st.LastInteractionTrackers, n)
     res = t("get_results (all)", eng.get_results, pc.output_nus, pc.output_energies, True, trackers=trk)
     print(f"  {'total':34s} {1e3 * (time.perf_counter() - t0):9.2f} ms   device {eng.last_propagate_ms():.2f} ms")
     t("get_results (no trackers)", eng.get_results, pc.output_nus, pc.output_energies, False)
