@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TARDIS_MC_ABI_VERSION 2  /* 2 (round 6): + tardis_mc_comm_check, tardis_mc_stream_results, tardis_mc_streamed_packets, microbench 15 */
+#define TARDIS_MC_ABI_VERSION 2  /* 2 (round 6): + tardis_mc_comm_check, tardis_mc_stream_results, tardis_mc_streamed_packets, tardis_mc_last_compactions, microbench 15 */
 
 enum {
     TARDIS_MC_OK = 0,
@@ -236,6 +236,10 @@ int tardis_mc_last_counters(TardisMcContext *ctx, int64_t out_counters[TARDIS_MC
  * 1 group-per-packet, 2 wave-owner with group sweeps, 3 wave-owner with lane sweeps, 4 wave-owner with the volley queue;
  * -1 before the first call. */
 int tardis_mc_last_variant(TardisMcContext *ctx);
+/* How often the last tardis_mc_propagate packed the live lanes of its drain into fewer waves (option "drain_compact" = T: once the packet supply has run out a wave
+ * suspends when T or fewer of its lanes still hold a packet; the live lanes of all waves are packed into full waves and the rest of the call runs as a launch of
+ * fewer waves, beside the line-estimator passes of the launch before; 0 = off.  Per-packet results do not depend on it). */
+int tardis_mc_last_compactions(TardisMcContext *ctx);
 /* Progress of the propagate call that is running (or of the last one): packets handed to the propagation kernel so far and the call's
  * packet count -- what the reference's packet progress bar shows (update_packets_pbar, modes/montecarlo_transport.py:94-120,
  * progress_bars.py).  Safe to call from ANOTHER host thread while tardis_mc_propagate blocks (it reads one device word on a stream of

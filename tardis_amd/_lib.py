@@ -37,6 +37,7 @@ SYMBOLS = {
     "tardis_mc_last_estimator_ms": (_i, [_vp, C.POINTER(C.c_double)]),
     "tardis_mc_last_counters": (_i, [_vp, C.POINTER(C.c_int64)]),
     "tardis_mc_last_variant": (_i, [_vp]),
+    "tardis_mc_last_compactions": (_i, [_vp]),
     "tardis_mc_progress": (_i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tardis_mc_get_results": (_i, [_vp, _vp]),
     "tardis_mc_pcg64_seed": (_i, [C.c_uint64, C.POINTER(C.c_uint64)]),

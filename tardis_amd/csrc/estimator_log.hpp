@@ -389,7 +389,11 @@ constexpr int ACCD_LONG = 255;                                 // longer records
 constexpr int ACCD_PASSES = 20;                                // >= 18 = the items of 64 records of ACCD_LONG lines (<= 5 + 8 + 5 each) / 64
 static_assert(ACCD_TILE % (1 << ACCD_TOP) == 0 && EST_TILE % (1 << ACCD_TOP) == 0, "whole top-level blocks, tiles aligned to them");
 
-template <bool FULL, bool DIRECT>
+// LOOP: every lane walks its own record from left to right -- at line p the largest aligned block that still fits, min(ctz(p | 32), floor(log2(end - p))): the same
+// blocks as the item list of the balanced form (ascending towards the split point, 32-line blocks across it, descending behind it) without the list: no scan over
+// the item counts, no staging, no item decoding -- ~20 instructions per block instead of ~100 per 64 items + ~110 per batch -- at the price of lanes idling while
+// the record with the most blocks in the wave finishes.
+template <bool FULL, bool DIRECT, bool LOOP = false>
 __global__ void __launch_bounds__(64 * ACCD_WAVES) accumulate_dyadic_kernel(const LineVisitRecord *__restrict__ records,
                                                                             const unsigned *__restrict__ sorted_index,
                                                                             const unsigned *__restrict__ bin_start,
@@ -473,14 +477,53 @@ __global__ void __launch_bounds__(64 * ACCD_WAVES) accumulate_dyadic_kernel(cons
                 }
             }
         };
+        // (an unconditional load from a clamped index: behind a branch the loads of the batches ahead cannot be counted and the wait for THIS batch's record
+        // becomes a wait for all of them -- vmcnt(0) with the prefetches just issued)
         auto fetch = [&](unsigned r) {
-            LineVisitRecord rec;
-            rec.c_e = rec.c_jb = 0.0; rec.idx0 = tile_idx0; rec.n = 0;
-            if (r < rec_last) rec = records[DIRECT ? r : sorted_index[r]];
+            const unsigned rc = min(r, rec_last - 1u);  // (rec_first < rec_last: a slice is never empty)
+            LineVisitRecord rec = records[DIRECT ? rc : sorted_index[rc]];
+            if (r >= rec_last) { rec.n = 0; rec.idx0 = tile_idx0; }
             return rec;
         };
         const unsigned stride = 64 * ACCD_WAVES;
         unsigned base = rec_first + (unsigned)w * 64;
+        // a record of more than ACCD_LONG lines: the whole wave walks its items (it may leave the LDS tile: add_item checks)
+        auto long_records = [&](const LineVisitRecord &rec) {
+            unsigned long long longs = __ballot(rec.n > (unsigned)ACCD_LONG);
+            while (longs) {
+                const int q = __builtin_ctzll(longs);
+                longs &= longs - 1;
+                const unsigned q_a = (unsigned)__shfl((int)(rec.idx0 - tile_idx0), q), q_n = (unsigned)__shfl((int)rec.n, q);
+                unsigned q_up, q_dn;
+                split(q_a, q_n, q_up, q_dn);
+                const unsigned q_m = n_items(q_up, q_dn);
+                const double l_ce = __shfl(rec.c_e, q), l_cjb = __shfl(rec.c_jb, q);
+                for (unsigned k = lane; k < q_m; k += 64) add_item(q_a, q_up, q_dn, k, l_cjb, l_ce);
+            }
+        };
+        if (LOOP) {
+            // (records of <= ACCD_LONG lines end inside the LDS tile and inside the shell's row: no bounds to check.  Two records per lane walked in one loop --
+            // the sum of two records' blocks varies less over the lanes than one record's -- was tried: the switch from the first to the second costs every
+            // iteration what the better balance gains.)
+            LineVisitRecord next = fetch(base + (unsigned)lane), next2 = fetch(base + stride + (unsigned)lane);
+            for (; base < rec_last; base += stride) {
+                const LineVisitRecord rec = next;
+                next = next2;
+                next2 = fetch(base + 2 * stride + (unsigned)lane);
+                unsigned p = rec.idx0 - tile_idx0;
+                const unsigned e = rec.n > (unsigned)ACCD_LONG ? p : p + rec.n;
+                const double cj = rec.c_jb, ce = rec.c_e;
+                while (p < e) {
+                    const unsigned fit = 31u - (unsigned)__builtin_clz(e - p);
+                    const unsigned lv = min((unsigned)__builtin_ctz(p | (1u << ACCD_TOP)), fit);
+                    const unsigned idx = 2u * ACCD_TILE - ((2u * ACCD_TILE) >> lv) + (p >> lv);
+                    atomicAdd(&acc_jb[idx], cj);
+                    atomicAdd(&acc_ed[idx], ce);
+                    p += 1u << lv;
+                }
+                long_records(rec);
+            }
+        } else {
         LineVisitRecord next = fetch(base + (unsigned)lane), next2 = fetch(base + stride + (unsigned)lane);  // (16 waves per CU: two batches ahead)
         for (; base < rec_last; base += stride) {
             const LineVisitRecord rec = next;
@@ -529,6 +572,7 @@ __global__ void __launch_bounds__(64 * ACCD_WAVES) accumulate_dyadic_kernel(cons
                 const double l_ce = __shfl(rec.c_e, q), l_cjb = __shfl(rec.c_jb, q);
                 for (unsigned k = lane; k < q_m; k += 64) add_item(q_a, q_up, q_dn, k, l_cjb, l_ce);
             }
+        }
         }
         __syncthreads();
         for (unsigned k = threadIdx.x; k < tile_len; k += 64 * ACCD_WAVES) {

@@ -204,6 +204,75 @@ __global__ void __launch_bounds__(64) late_list_kernel(const LaneSave *__restric
     }
 }
 
+// ---- drain compaction.  Once the packet supply has run out the lanes of a wave fall idle one by one while the wave keeps its place on the chip to the end of its
+// longest packet: a chip full of resident waves with a handful of live lanes each, and no room beside them for the estimator passes of the epoch that has just ended.
+// With WaveCold::drain_split = T the waves suspend when T or fewer of their lanes are left; the kernels below then pack the live lanes of all suspended waves into
+// waves of 64 -- a lane's whole state is its LaneSave record and its MT19937 state buffer, neither depends on the place in the grid -- and the rest of the call runs
+// as a launch of a quarter of the waves (or fewer) beside the passes.
+// census: [0] live lanes, [1] packets reserved but not started, [2] waves not done, [3] lanes waiting for a packet (must be 0 where [1] is: nothing left to hand out)
+__global__ void __launch_bounds__(64) drain_census_kernel(const LaneSave *__restrict__ save, const WaveSave *__restrict__ wsave, int waves, long long n_packets,
+                                                          unsigned *__restrict__ out)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (w >= waves) return;
+    const WaveSave ws = wsave[w];
+    if (ws.done) return;
+    const int state = save[(size_t)w * 64 + lane].state;
+    const unsigned n_live = (unsigned)__popcll(__ballot(state != WS_NEED_PACKET && state != WS_DONE));
+    const unsigned n_need = (unsigned)__popcll(__ballot(state == WS_NEED_PACKET));
+    const long long r1 = ws.res_end < n_packets ? ws.res_end : n_packets;
+    if (lane == 0) {
+        if (n_live) atomicAdd(out, n_live);
+        if (r1 > ws.res_next) atomicAdd(out + 1, (unsigned)(r1 - ws.res_next));
+        atomicAdd(out + 2, 1u);
+        if (n_need) atomicAdd(out + 3, n_need);
+    }
+}
+// live lanes of wave w -> consecutive places of the packed grid (the order is that of the atomics: a packet's results do not depend on its place)
+__global__ void __launch_bounds__(64) drain_compact_kernel(const LaneSave *__restrict__ save, const WaveSave *__restrict__ wsave, const uint32_t *__restrict__ states, int waves,
+                                                           LaneSave *__restrict__ dst_save, uint32_t *__restrict__ dst_states, unsigned *__restrict__ counter)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (w >= waves) return;
+    const WaveSave ws = wsave[w];
+    if (ws.done) return;
+    const int state = save[(size_t)w * 64 + lane].state;
+    const bool live = state != WS_NEED_PACKET && state != WS_DONE;
+    const unsigned long long lm = __ballot(live);
+    if (!lm) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(counter, (unsigned)__popcll(lm));
+    base = (unsigned)__shfl((int)base, 0);
+    if (live) dst_save[base + (unsigned)__popcll(lm & ((1ull << lane) - 1ull))] = save[(size_t)w * 64 + lane];
+    // the MT19937 state buffers of the live lanes, one after the other, 64 words at a time
+    unsigned k = 0;
+    for (unsigned long long m = lm; m; m &= m - 1ull, ++k) {
+        const int src_lane = __ffsll((long long)m) - 1;
+        const uint32_t *from = states + ((size_t)w * 64 + (size_t)src_lane) * WV_STATE_STRIDE;
+        uint32_t *to = dst_states + (size_t)(base + k) * WV_STATE_STRIDE;
+        for (int i = lane; i < WV_STATE_STRIDE; i += 64) to[i] = from[i];
+    }
+}
+// the packed grid's wave records, and the idle lanes behind the last live one
+__global__ void __launch_bounds__(256) drain_compact_finish_kernel(LaneSave *__restrict__ dst_save, WaveSave *__restrict__ dst_wsave, const unsigned *__restrict__ counter,
+                                                                  long long n_packets)
+{
+    const unsigned total = *counter, waves = (total + 63u) / 64u;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= waves * 64u) return;
+    if (i >= total) {
+        LaneSave idle{};
+        idle.state = WS_DONE;
+        dst_save[i] = idle;
+    }
+    if ((i & 63u) == 0u) {
+        WaveSave ws;
+        ws.res_next = ws.res_end = n_packets; ws.exhausted = 1; ws.done = 0; ws.log_chunk = -1; ws.log_gen = 0;
+        for (int k = 0; k < 7; ++k) ws.cnt[k] = 0ull;
+        dst_wsave[i >> 6] = ws;
+    }
+}
+
 // One worker slot of a group: the trace it is sweeping (group-uniform values) and this lane's line of the current chunk.
 struct SweepSlot {
     int owner;  // lane (in this wave) of the packet being traced, -1: idle
@@ -984,7 +1053,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             const unsigned long long can = __ballot(state != WS_DONE && !(state == WS_VOLLEY && vq_fresh));
             vq_stop = waiting != 0ull && __popcll(can) <= H.vq_min_active;
         }
-        const bool drain_stop = W->drain_split && W->save && exhausted && res_next == res_end && logged_any && __ballot(state != WS_DONE) != 0ull;
+        // (drain_split = T: once T or fewer lanes are left -- 64: as soon as the supply has run out)
+        const int drain_live = W->drain_split ? __popcll(__ballot(state != WS_DONE)) : 0;
+        const bool drain_stop = W->drain_split && W->save && exhausted && res_next == res_end && logged_any && drain_live != 0 && drain_live <= W->drain_split;
         if (log_full || vq_stop || drain_stop) {
             // this wave's region of the line-visit log is full (or its lanes wait for the v-packet tracer): suspend the lanes as
             // they are (every lane is at the top of a pass: a swept trace waiting for its event, a lane sweep in progress, a

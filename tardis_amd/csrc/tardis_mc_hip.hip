@@ -197,7 +197,7 @@ struct TardisMcContext {
     int group_size = 0;  // 0: automatic (8 or 16 lanes per packet)
     int log_tail_packets = 8;               // tail split: packets' worth of traces a lane in flight still logs after the supply has run out
     int log_tail_split = 1;                 // plan the epochs so that the last one holds only the drain of the call (see tardis_mc_propagate)
-    int est_accumulate = 2;                 // accumulate kernel: 2 dyadic hierarchy of block sums (accumulate_dyadic_kernel), 1 8-line block sums (accumulate_blocks_kernel), 0 one add per line visit (accumulate_kernel, index pipeline only)
+    int est_accumulate = 3;                 // accumulate kernel: 3 dyadic hierarchy of block sums, a lane per record (accumulate_dyadic_kernel<.., LOOP>), 2 the same with the blocks of 64 records spread over the lanes, 1 8-line block sums (accumulate_blocks_kernel), 0 one add per line visit (accumulate_kernel, index pipeline only)
     int est_pipeline = 1;                   // line-estimator passes: 1 two-level partition of the records (estimator_partition.hpp), 0 index sort + gather (estimator_log.hpp)
     DevBuf log_part;                        // est_pipeline 1: the scratch copy of one epoch's records, shared by both buffer sets
     long long log_chunk_records = 0;        // records per chunk of the line-visit log's pool (0: automatic, <= 4096; tests)
@@ -234,6 +234,11 @@ struct TardisMcContext {
     std::vector<mc::WaveCold> wave_cold_host;
     // wave kernel: a propagate call is a sequence of epochs over one packet supply (LaneSave, propagate_wave.hpp)
     DevBuf lane_save, wave_save, suspended_dev;
+    // drain compaction (option drain_compact = T: waves suspend once the supply has run out and T or fewer of their lanes are left; the live lanes are packed into
+    // full waves and the rest of the call is a launch of fewer waves, beside the estimator passes): the packed grid's buffers, two sets for repeated packing
+    int drain_compact = 0;
+    DevBuf lane_save_c[2], wave_save_c[2], seeded_states_c[2], drain_census;
+    int compactions = 0;  // of the last propagate call
     DevBuf vq_req, vq_items, vq_count, vq_jsave;  // volley queue (variant 4, propagate_wave.hpp: VolleyRequest)
     long long vq_min_items = -1;  // switch the queue off for the rest of a call once a launch requests fewer v-packets (-1: automatic)
     int vq_min_active = 8, vq_oversubscribe = 4, vq_tracer_waves_per_simd = 6;
@@ -806,6 +811,8 @@ void tardis_mc_destroy(TardisMcContext *ctx)
     ctx->hot_sec.release(); ctx->hot_mass.release(); ctx->hot_flag.release(); ctx->blk_tab.release();
     ctx->tau_pfx.release(); ctx->tau_rowsum.release(); ctx->pfx_flag.release(); ctx->nt_t.release();
     ctx->lane_save.release(); ctx->wave_save.release(); ctx->suspended_dev.release();
+    for (int k = 0; k < 2; ++k) { ctx->lane_save_c[k].release(); ctx->wave_save_c[k].release(); ctx->seeded_states_c[k].release(); }
+    ctx->drain_census.release();
     ctx->vq_req.release(); ctx->vq_items.release(); ctx->vq_count.release(); ctx->vq_jsave.release();
     if (ctx->suspended_host) (void)hipHostFree(ctx->suspended_host);
     for (hipEvent_t e : ctx->ev_post) if (e) (void)hipEventDestroy(e);
@@ -846,6 +853,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vpacket_log_capacity") { ctx->vlog_capacity = value; ctx->vlog_capacity_user = value > 0; }
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "drain_split") ctx->drain_split = value ? 1 : 0;
+    else if (n == "drain_compact") ctx->drain_compact = (int)std::max<long long>(0, std::min<long long>(48, value));
     else if (n == "walk_sector_packing") ctx->walk_sector_packing = value ? 1 : 0;
     else if (n == "walk_hot") ctx->walk_hot = value < 0 ? -1 : (value ? 1 : 0);  // (like walk_sector_packing: before set_opacity)
     else if (n == "walk_hot_min_mass") ctx->walk_hot_min_mass = (int)std::max<long long>(0, std::min<long long>(value, 1001));
@@ -873,7 +881,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "vpk_wide_registers") ctx->vpk_wide_registers = (int)std::max<long long>(0, std::min<long long>(value, 2));
     else if (n == "bucket_lines_permille") ctx->bucket_lines_permille = (int)std::max<long long>(50, std::min<long long>(value, 16000));
     else if (n == "vp_carry_min_active") ctx->vp_carry_min_active = (int)std::max<long long>(0, std::min<long long>(value, 63));
-    else if (n == "est_accumulate") ctx->est_accumulate = (int)std::max<long long>(0, std::min<long long>(value, 2));
+    else if (n == "est_accumulate") ctx->est_accumulate = (int)std::max<long long>(0, std::min<long long>(value, 3));
     else if (n == "log_tail_packets") ctx->log_tail_packets = (int)std::max<long long>(0, std::min<long long>(value, 1000));
     else if (n == "log_chunk_records") ctx->log_chunk_records = value <= 0 ? 0 : std::max<long long>(256, std::min<long long>(value, 1 << 20));
     else if (n == "walk_min_active") {  // (-1: never carry a walk over; < -1: the automatic choice again)
@@ -1441,6 +1449,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
     if (!ctx->have_geometry || !ctx->have_opacity || !ctx->have_config || !ctx->have_packets)
         return fail(ctx, TARDIS_MC_ERR_STATE, "set_geometry/set_opacity/set_config/set_packets must precede propagate");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->compactions = 0;
     const bool rs_armed = ctx->rs.armed;  // (tardis_mc_stream_results holds for one call)
     ctx->rs.armed = false; ctx->rs.valid = false; ctx->rs.upto = 0; ctx->rs.n_late = 0;
     const int tune_pending = ctx->ls_tune.pending;  // (the lane-sweep tuner: whether the previous propagate call was one of its timed ones: 2 * instantiation + sample)
@@ -1834,8 +1843,14 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             // -- so that no later call of the same size allocates tens of GB in the middle of an iteration)
             const bool tail_possible = ctx->log_tail_split && !vq && ctx->log_sets != 1 && region_capacity > 0 &&
                                        (double)n * std::max(ctx->traces_per_packet, 16.0) >= 5e8;
-            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((tail_plan || tail_possible || want_split || (region_capacity > 0 && (unsigned long long)region_capacity * n_chunks < (unsigned long long)((double)n * ctx->log_budget_per_packet))) ? 2 : 1);
-            bool split_armed = want_split;
+            // ... or packs the drain's live lanes into fewer waves (drain_compact): the passes of the launch before run beside the packed drain
+            const bool want_compact = ctx->drain_compact > 0 && !vq && !vpk && !cu_split && !shell_log && ctx->log_sets != 1 && region_capacity > 0 && n > 64LL * (waves - 1) && waves >= 8;
+            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((tail_plan || tail_possible || want_split || want_compact || (region_capacity > 0 && (unsigned long long)region_capacity * n_chunks < (unsigned long long)((double)n * ctx->log_budget_per_packet))) ? 2 : 1);
+            bool split_armed = want_split && !want_compact;
+            bool compact_armed = want_compact;
+            int waves_cur = waves;  // (the grid of the next launch: smaller after a compaction)
+            mc::LaneSave *cur_save = nullptr; mc::WaveSave *cur_wsave = nullptr; uint32_t *cur_states = nullptr;  // (set below, once the buffers exist)
+            ctx->compactions = 0;
             const size_t set_records = (size_t)std::max<unsigned long long>((unsigned long long)region_capacity * n_chunks, 1);
             for (int b = 0; b < n_sets; ++b) {
                 HIP_TRY(ctx, ctx->log_records[b].ensure(set_records * sizeof(mc::LineVisitRecord)));
@@ -1874,7 +1889,9 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             HIP_TRY(ctx, ctx->lane_save.ensure((size_t)waves * 64 * sizeof(mc::LaneSave)));
             HIP_TRY(ctx, ctx->wave_save.ensure((size_t)waves * sizeof(mc::WaveSave)));
             HIP_TRY(ctx, ctx->suspended_dev.ensure(4 * sizeof(unsigned)));
-            if (!ctx->suspended_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->suspended_host, 8 * sizeof(unsigned), hipHostMallocDefault));
+            cur_save = ctx->lane_save.as<mc::LaneSave>(); cur_wsave = ctx->wave_save.as<mc::WaveSave>(); cur_states = ctx->seeded_states.as<uint32_t>();
+            if (want_compact) HIP_TRY(ctx, ctx->drain_census.ensure(8 * sizeof(unsigned)));
+            if (!ctx->suspended_host) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->suspended_host, 16 * sizeof(unsigned), hipHostMallocDefault));
             if (vq) {
                 HIP_TRY(ctx, ctx->vq_req.ensure((size_t)waves * 64 * sizeof(mc::VolleyRequest)));
                 HIP_TRY(ctx, ctx->vq_items.ensure((size_t)waves * 64 * mc::VP_ROUND * sizeof(unsigned)));
@@ -1961,6 +1978,15 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                                        (const unsigned *)nullptr, 0, 0u, bin_start + n_bins, lg.tiles_per_shell, ctx->n_lines, bits_of(mc::PART_LOCAL_BUCKETS),
                                        bin_fill, lg.records);
                     }
+                    if (ctx->est_accumulate == 3) {  // the dyadic hierarchy, a lane per record (accumulate_dyadic_kernel<.., LOOP>: 73 KB of LDS, two workgroups per CU)
+                        if (full)
+                            hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<true, true, true>), dim3(cus * 2), dim3(64 * mc::ACCD_WAVES), 0, es, binned,
+                                               (const unsigned *)nullptr, bin_start, slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                        else
+                            hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<false, true, true>), dim3(cus * 2), dim3(64 * mc::ACCD_WAVES), 0, es, binned,
+                                               (const unsigned *)nullptr, bin_start, slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                        return hipGetLastError();
+                    }
                     if (ctx->est_accumulate == 2) {  // the dyadic hierarchy of block sums (accumulate_dyadic_kernel): one workgroup per CU
                         if (full)
                             hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<true, true>), dim3(cus), dim3(64 * mc::ACCD_WAVES), 0, es, binned,
@@ -1980,6 +2006,15 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 }
                 hipLaunchKernelGGL(mc::bin_scatter_kernel, dim3(bin_blocks), dim3(256), hist_lds, es, lg.keys, lg.region_count, lg.n_regions,
                                    lg.region_capacity, n_bins, bin_fill, sorted);
+                if (ctx->est_accumulate == 3) {
+                    if (full)
+                        hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<true, false, true>), dim3(cus * 2), dim3(64 * mc::ACCD_WAVES), 0, es, lg.records, sorted, bin_start,
+                                           slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                    else
+                        hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<false, false, true>), dim3(cus * 2), dim3(64 * mc::ACCD_WAVES), 0, es, lg.records, sorted, bin_start,
+                                           slice_start, n_bins, lg.tiles_per_shell, ctx->n_lines, P.nu_line, P.jblue_t, P.edot_t);
+                    return hipGetLastError();
+                }
                 if (ctx->est_accumulate == 2) {
                     if (full)
                         hipLaunchKernelGGL((mc::accumulate_dyadic_kernel<true, false>), dim3(cus), dim3(64 * mc::ACCD_WAVES), 0, es, lg.records, sorted, bin_start,
@@ -2075,16 +2110,16 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 HIP_TRY(ctx, hipMemsetAsync(ctx->suspended_dev.p, 0, 4 * sizeof(unsigned), st));
                 if (vq) HIP_TRY(ctx, hipMemsetAsync(ctx->vq_count.p, 0, 2 * sizeof(unsigned), st));
                 mc::WaveCold &wc = ctx->wave_cold_host[epoch & 1];
-                wc.P = P; wc.D = F; wc.log = lg; wc.seeded_states = ctx->seeded_states.as<uint32_t>();
+                wc.P = P; wc.D = F; wc.log = lg; wc.seeded_states = cur_states;
                 wc.chunk_first = 0; wc.chunk_count = n;
                 wc.launch = ctx->seed_chk[0].as<mc::LaunchRec>();
                 wc.vp_scratch = ctx->vp_scratch[0].as<mc::VpResult>();
                 wc.vp_park = (vpk && !vq_on && ctx->vp_carry_min_active > 0) ? ctx->vp_park.as<mc::VpPark>() : nullptr;
                 wc.vp_carry_min_active = ctx->vp_carry_min_active; wc.vp_pad = 0;
-                wc.save = may_suspend ? ctx->lane_save.as<mc::LaneSave>() : nullptr;
-                wc.wsave = may_suspend ? ctx->wave_save.as<mc::WaveSave>() : nullptr;
+                wc.save = may_suspend ? cur_save : nullptr;
+                wc.wsave = may_suspend ? cur_wsave : nullptr;
                 wc.resume = epoch > 0 ? 1 : 0;
-                wc.drain_split = split_armed ? 1 : 0;
+                wc.drain_split = split_armed ? 64 : (compact_armed ? ctx->drain_compact : 0);  // (the most live lanes a wave whose supply has run out suspends with)
                 wc.suspended = ctx->suspended_dev.as<unsigned>();
                 wc.vq_req = vq_on ? ctx->vq_req.as<mc::VolleyRequest>() : nullptr;
                 wc.vq_items = vq_on ? ctx->vq_items.as<unsigned>() : nullptr;
@@ -2096,8 +2131,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 HIP_TRY(ctx, store_value(st, wc_dev, wc));
                 // split launch (see epoch_split): the estimator passes of the previous epoch are queued (or running) on the second stream
                 // (not the drain launch of a tail-split call: its lanes are the call's critical path, half of them would start behind the bulk's passes)
-                const bool split = ctx->epoch_split && !vq && !cu_masked && !tail_plan && n_sets == 2 && epoch > 0 && es != st && ctx->post_pending[b ^ 1] && waves >= 8 * cus;
-                const int waves1 = split ? waves / 2 : waves;
+                const bool split = ctx->epoch_split && !want_compact && !vq && !cu_masked && !tail_plan && n_sets == 2 && epoch > 0 && es != st && ctx->post_pending[b ^ 1] && waves >= 8 * cus;
+                const int waves1 = split ? waves / 2 : waves_cur;
                 if (split) HIP_TRY(ctx, hipEventRecord(ctx->ev_split[0], st));  // (pool, counters and argument block of this epoch are in place)
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[2], st));
                 hipLaunchKernelGGL(kw, dim3(waves1), dim3(64), wave_lds, st, hot, (const mc::WaveCold *)wc_dev);
@@ -2203,12 +2238,41 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 if (*ctx->suspended_host == 0) { call_complete = true; break; }
                 records_done += (double)std::min<unsigned long long>((unsigned long long)ctx->suspended_host[6], pool_chunks) * (double)region_capacity;
                 if (ctx->suspended_host[2] > 0) split_armed = false;  // (the drain has been split off: the next launch runs to the end)
+                if (compact_armed && ctx->suspended_host[2] > 0) {
+                    // some waves have suspended with few live lanes: what is left on the grid?
+                    unsigned *cen = ctx->drain_census.as<unsigned>();
+                    HIP_TRY(ctx, hipMemsetAsync(cen, 0, 8 * sizeof(unsigned), st));
+                    hipLaunchKernelGGL(mc::drain_census_kernel, dim3(waves_cur), dim3(64), 0, st, cur_save, cur_wsave, waves_cur, n, cen);
+                    HIP_TRY(ctx, hipGetLastError());
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host + 8, cen, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(ctx, hipStreamSynchronize(st));
+                    const unsigned live = ctx->suspended_host[8], reserved = ctx->suspended_host[9], waiting = ctx->suspended_host[11];
+                    const int packed = (int)((live + 63u) / 64u);
+                    // (only when nothing is left to hand out, and when it frees more than half of the grid)
+                    if (reserved == 0 && waiting == 0 && live > 0 && 2 * packed <= waves_cur) {
+                        const int g = ctx->compactions & 1;
+                        HIP_TRY(ctx, ctx->lane_save_c[g].ensure((size_t)packed * 64 * sizeof(mc::LaneSave)));
+                        HIP_TRY(ctx, ctx->wave_save_c[g].ensure((size_t)packed * sizeof(mc::WaveSave)));
+                        HIP_TRY(ctx, ctx->seeded_states_c[g].ensure((size_t)packed * 64 * mc::WV_STATE_STRIDE * sizeof(uint32_t)));
+                        HIP_TRY(ctx, hipMemsetAsync(cen + 4, 0, sizeof(unsigned), st));
+                        hipLaunchKernelGGL(mc::drain_compact_kernel, dim3(waves_cur), dim3(64), 0, st, (const mc::LaneSave *)cur_save, (const mc::WaveSave *)cur_wsave,
+                                           (const uint32_t *)cur_states, waves_cur, ctx->lane_save_c[g].as<mc::LaneSave>(), ctx->seeded_states_c[g].as<uint32_t>(), cen + 4);
+                        HIP_TRY(ctx, hipGetLastError());
+                        hipLaunchKernelGGL(mc::drain_compact_finish_kernel, dim3((unsigned)((packed * 64 + 255) / 256)), dim3(256), 0, st, ctx->lane_save_c[g].as<mc::LaneSave>(),
+                                           ctx->wave_save_c[g].as<mc::WaveSave>(), (const unsigned *)(cen + 4), n);
+                        HIP_TRY(ctx, hipGetLastError());
+                        cur_save = ctx->lane_save_c[g].as<mc::LaneSave>(); cur_wsave = ctx->wave_save_c[g].as<mc::WaveSave>(); cur_states = ctx->seeded_states_c[g].as<uint32_t>();
+                        waves_cur = packed;
+                        ctx->compactions += 1;
+                        if (packed < 2 * cus) compact_armed = false;  // (nothing left worth freeing)
+                    }
+                }
                 if (streaming) {
                     // packets [0, handed) have been handed out; those of them still in flight (suspended lanes, reserved blocks) go on the late list, the range
                     // [upto, handed) is unpacked now -- in front of the next launch on the same stream -- and copied by the host beside that launch
                     const long long handed = (long long)std::min<unsigned long long>(*ctx->rs_next_host, (unsigned long long)n);
                     if (handed - ctx->rs.upto >= ctx->rs_min_packets) {
-                        hipLaunchKernelGGL(mc::late_list_kernel, dim3(waves), dim3(64), 0, st, ctx->lane_save.as<mc::LaneSave>(), ctx->wave_save.as<mc::WaveSave>(), waves, ctx->rs.upto, handed,
+                        hipLaunchKernelGGL(mc::late_list_kernel, dim3(waves_cur), dim3(64), 0, st, (const mc::LaneSave *)cur_save, (const mc::WaveSave *)cur_wsave, waves_cur, ctx->rs.upto, handed,
                                            ctx->rs_late.as<unsigned>(), ctx->rs_late_count.as<unsigned>(), ctx->rs.late_capacity);
                         HIP_TRY(ctx, hipGetLastError());
                         if (ctx->track) {
@@ -2440,6 +2504,7 @@ int tardis_mc_last_counters(TardisMcContext *ctx, int64_t out_counters[TARDIS_MC
 }
 
 int tardis_mc_last_variant(TardisMcContext *ctx) { return ctx ? ctx->last_variant : -1; }
+int tardis_mc_last_compactions(TardisMcContext *ctx) { return ctx ? ctx->compactions : -1; }
 
 int tardis_mc_last_estimator_ms(TardisMcContext *ctx, double *out_ms)
 {
@@ -2609,6 +2674,7 @@ int tardis_mc_run(TardisMcContext *ctx, const TardisMcPackets *packets, const Ta
     if (result && result->vpacket_log_capacity > 0) { ctx->vlog_capacity = result->vpacket_log_capacity; ctx->vlog_capacity_user = true; }
     if ((rc = tardis_mc_set_packets(ctx, packets))) return rc;
     if ((rc = tardis_mc_reset_estimators(ctx))) return rc;
+    if (result && (rc = tardis_mc_stream_results(ctx, result))) return rc;  // (the result arrays are known from the start: filled launch by launch)
     if ((rc = tardis_mc_propagate(ctx))) return rc;
     if ((rc = tardis_mc_synchronize(ctx))) return rc;
     return tardis_mc_get_results(ctx, result);

@@ -141,6 +141,10 @@ class Engine:
         self._check(self._L.tardis_mc_last_estimator_ms(self._h, C.byref(e)), "last_estimator_ms")
         return {"seed_ms": a.value, "propagate_ms": b.value, "launches": n.value, "estimator_ms": e.value}
 
+    def last_compactions(self) -> int:
+        """How often the last propagate() packed the live lanes of its drain into fewer waves (option drain_compact)."""
+        return int(self._L.tardis_mc_last_compactions(self._h))
+
     def last_variant(self) -> int:
         """Propagation kernel of the last propagate(): 0 lane, 1 group, 2 wave + group sweeps, 3 wave + lane sweeps,
         4 wave + volley queue (v-packets traced by vpacket_trace_kernel between its launches)."""

@@ -1,0 +1,125 @@
+"""Drain compaction (round 6; option `drain_compact` = T, include/tardis_mc.h: tardis_mc_last_compactions).
+
+Once the packet supply of a call has run out, the lanes of a wave fall idle one by one while the wave stays resident to the end of its longest packet
+(montecarlo_main_loop's prange has no such tail: a thread simply takes the next packet, modes/montecarlo_transport.py:108-173).  With the option a wave
+suspends when T or fewer of its lanes still hold a packet, the live lanes of all waves are packed into full waves (drain_compact_kernel: a lane is its
+LaneSave record + its MT19937 state buffer) and the rest of the call runs as a launch of fewer waves.  Scheduling only: which wave and lane finishes a
+packet decides nothing about the packet -- same bits per packet as the oracle, estimators to the summation-order tolerance, counters exact; with several
+epochs (lanes suspended in the middle of a sweep, then moved), with result streaming (the late list is taken from the packed grid), repeated packing, and
+thresholds that pack nothing."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import _golden
+from tardis_amd import state as st
+from tardis_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+EST_RTOL = 1e-11
+
+
+def _oracle(oracle, prob):
+    return oracle.run(prob.packet_collection, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
+                      prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE, n_threads=oracle.max_threads())
+
+
+def _run(prob, stream=False, **options):
+    from tardis_amd.engine import Engine
+    P = prob.packet_collection.initial_nus.size
+    out_nu, out_en, trk = np.full(P, -7.0), np.full(P, -7.0), st.LastInteractionTrackers(P)
+    with Engine(0) as eng:
+        for k, v in options.items():
+            eng.set_option(k, v)
+        eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+        eng.reset_estimators()
+        if stream:
+            eng.stream_results(out_nu, out_en, trk)
+        eng.propagate(); eng.synchronize()
+        res = eng.get_results(out_nu, out_en, track_last_interaction=True, trackers=trk)
+        return res, eng.last_compactions(), eng.last_kernel_times()["launches"], eng.last_variant(), eng.streamed_packets()
+
+
+def _same(got, ref):
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    for f in st.LastInteractionTrackers.I64_FIELDS:
+        assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f)), f
+    for f in st.LastInteractionTrackers.F64_FIELDS:
+        assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f), equal_nan=True), f
+    assert_allclose(got.j_estimator, ref.j_estimator, rtol=EST_RTOL)
+    assert_allclose(got.nu_bar_estimator, ref.nu_bar_estimator, rtol=EST_RTOL)
+    assert_allclose(got.j_blue_estimator, ref.j_blue_estimator, rtol=EST_RTOL)
+    assert_allclose(got.edotlu_estimator, ref.edotlu_estimator, rtol=EST_RTOL)
+    for k in ("line_visits", "events", "macro_transitions", "rng_draws"):
+        assert got.counters[k] == ref.counters[k], k
+
+
+PROBLEMS = [
+    dict(seed=51, n_packets=40_000, n_shells=20, n_lines=30_000, line_interaction_type="macroatom"),
+    dict(seed=52, n_packets=24_000, n_shells=20, n_lines=500_000, line_interaction_type="macroatom", level_sizes="heavy"),
+    dict(seed=53, n_packets=60_000, n_shells=12, n_lines=20_000, line_interaction_type="downbranch"),
+    dict(seed=54, n_packets=30_000, n_shells=5, n_lines=37, line_interaction_type="scatter"),
+]
+
+
+@pytest.mark.parametrize("wps", [4, 3])
+@pytest.mark.parametrize("kw", PROBLEMS, ids=["macroatom", "heavy", "downbranch", "scatter-37-lines"])
+def test_packed_drain_matches_the_oracle(oracle, kw, wps):
+    prob = synthetic.make_problem(**kw)
+    ref = _oracle(oracle, prob)
+    got, packed, launches, variant, _ = _run(prob, drain_compact=16, ls_waves_per_simd=wps)
+    assert variant == 3 and packed >= 1 and launches >= 2
+    _same(got, ref)
+
+
+@pytest.mark.parametrize("threshold", [2, 8, 32, 48])
+def test_thresholds(oracle, threshold):
+    """2: the waves run on until nearly nothing is left (the packed grid is a handful of waves); 48: waves suspend early, packing frees less than half of the grid
+    and is not done -- the waves resume as they are and the drain goes on (suspending again once they have logged something)."""
+    prob = synthetic.make_problem(**PROBLEMS[0])
+    ref = _oracle(oracle, prob)
+    got, packed, launches, _, _ = _run(prob, drain_compact=threshold)
+    assert launches >= 2
+    if threshold <= 8:
+        assert packed >= 1
+    _same(got, ref)
+
+
+def test_packing_between_epochs_and_with_streamed_results(oracle):
+    """A log too small for the call (many epochs; a launch can end with some waves out of log space and others out of packets), result streaming on: the
+    ranges copied early and the late list -- taken from the PACKED grid after a compaction -- give the same arrays."""
+    prob = synthetic.make_problem(seed=55, n_packets=600_000, n_shells=20, n_lines=30_000, line_interaction_type="macroatom")
+    plain, p0, _, _, _ = _run(prob)
+    assert p0 == 0
+    for stream in (False, True):
+        got, packed, launches, _, (streamed, _resent) = _run(prob, stream=stream, drain_compact=16, log_capacity=1 << 22, stream_min_packets=4096)
+        assert packed >= 1 and launches >= 4
+        assert (streamed > 0) == stream
+        _same(got, plain)
+        assert not np.any(got.output_nus == -7.0)
+
+
+def test_repeated_packing(oracle):
+    """Enough lanes for the packed grid to be worth packing again (it is re-armed while it holds at least two waves per CU)."""
+    prob = synthetic.make_problem(seed=56, n_packets=400_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+    plain, _, _, _, _ = _run(prob)
+    got, packed, launches, _, _ = _run(prob, drain_compact=16)
+    assert packed >= 2 and launches >= 3
+    _same(got, plain)
+
+
+@pytest.mark.parametrize("name", [n for n in _golden.CASES if "_nv0" in n])
+def test_packed_drain_on_the_goldens(name):
+    from tardis_amd.engine import Engine
+    prob, g = _golden.load_case(name)
+    with Engine(0) as eng:
+        eng.set_option("drain_compact", 8)
+        eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        got = eng.get_results(track_last_interaction=True)
+    assert_allclose(got.output_nus, g["output_nus"], rtol=1e-13, atol=0)
+    assert_allclose(got.output_energies, g["output_energies"], rtol=1e-13, atol=0)
+    for f in _golden.TRACKER_I64:
+        assert np.array_equal(getattr(got.trackers, f), g["trk_" + f]), f

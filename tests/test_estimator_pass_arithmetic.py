@@ -195,3 +195,21 @@ def test_dyadic_cells_and_flush():
     k = np.arange(T)
     got = sum(acc[off[l] + (k >> l)] for l in range(TOP + 1))
     assert np.array_equal(got, truth)
+
+
+def test_the_greedy_walk_visits_the_items_blocks():
+    """accumulate_dyadic_kernel<.., LOOP> (est_accumulate 3) has no item list: a lane walks its record from the left, at line p the block of
+    min(ctz(p | 32), floor(log2(end - p))) levels.  Same blocks as the item list -- ascending to the split point, 32-line blocks across it, descending
+    behind it (the list numbers those from the smallest up, the walk meets them from the largest down)."""
+    for a in list(range(0, 70)) + [1023, 1024, 2015, 2047]:
+        for n in range(1, 256):
+            up, dn = _split(a, n)
+            m = bin(up & 31).count("1") + (up >> 5) + (dn >> 5) + bin(dn & 31).count("1")
+            items = [_dyadic_item(a, up, dn, j) for j in range(m)]
+            walk, p, e = [], a, a + n
+            while p < e:
+                ctz = ((p | (1 << TOP)) & -(p | (1 << TOP))).bit_length() - 1
+                lv = min(ctz, (e - p).bit_length() - 1)
+                walk.append((lv, p))
+                p += 1 << lv
+            assert sorted(walk) == sorted(items) and len(set(walk)) == len(walk), (a, n)

@@ -26,7 +26,7 @@ from tardis_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 EST_RTOL = 1e-11
-MODES = [(1, 1), (1, 2), (0, 1), (0, 2), (0, 0)]  # (est_pipeline, est_accumulate); accumulate 2 = the dyadic hierarchy of round 6
+MODES = [(1, 1), (1, 2), (0, 1), (0, 2), (0, 0), (1, 3), (0, 3)]  # (est_pipeline, est_accumulate); accumulate 2 / 3 = the dyadic hierarchy of round 6: items spread over the lanes / a lane per record
 
 
 def _oracle(oracle, prob, trace_log=None):

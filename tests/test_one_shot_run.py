@@ -97,3 +97,22 @@ def test_one_shot_run_reports_the_reference_errors(oracle):
         with pytest.raises(MonteCarloException) as ei:
             eng.run(prob.packet_collection, prob.geometry, prob.time_explosion, bad, prob.montecarlo_configuration, prob.spectrum_frequency_grid)
         assert ei.value.packet_index >= 0
+
+
+@pytest.mark.gpu
+def test_the_one_shot_call_streams_its_results(oracle):
+    """tardis_mc_run knows the result arrays from the start: a call of several launches fills them launch by launch (tardis_mc_stream_results) --
+    same bits as the oracle's."""
+    from tardis_amd import synthetic
+    from tardis_amd.engine import Engine
+    prob = synthetic.make_problem(seed=41, n_packets=700_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+    ref = oracle.run(prob.packet_collection, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
+                     prob.spectrum_frequency_grid, math_mode=oracle.MATH_PORTABLE, n_threads=oracle.max_threads())
+    with Engine(0) as eng:
+        eng.set_option("log_capacity", 1 << 21); eng.set_option("stream_min_packets", 4096)
+        got = eng.run(prob.packet_collection, prob.geometry, prob.time_explosion, prob.opacity_state, prob.montecarlo_configuration,
+                      prob.spectrum_frequency_grid)
+        assert eng.streamed_packets()[0] > 0 and eng.last_kernel_times()["launches"] >= 3
+    assert np.array_equal(got.output_nus, ref.output_nus) and np.array_equal(got.output_energies, ref.output_energies)
+    for f in ("shell_id", "interaction_type", "interaction_line_absorb_id", "interaction_line_emit_id", "interactions_count"):
+        assert np.array_equal(getattr(got.trackers, f), getattr(ref.trackers, f)), f
