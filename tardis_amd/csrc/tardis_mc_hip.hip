@@ -247,7 +247,7 @@ struct TardisMcContext {
     bool wave_epoch_mode = false, post_pending[2] = {false, false}, prop_pending = false;
     double sum_seed_ms = 0.0, sum_prop_ms = 0.0, sum_post_ms = 0.0;
     int launches = 0;
-    int log_sets = 2;
+    int log_sets = 0;  // 2: the estimator passes of an epoch run beside the next launch (two log sets); 1: before it (one set); 0: 1 for calls of several epochs, 2 otherwise
     int last_variant = -1;  // kernel of the last propagate call (see tardis_mc_last_variant)
     int waves_per_simd = 4;  // register budget hint of the cooperative kernel (2: 256 VGPRs, 3: 168, 4: 128)
     // result streaming (tardis_mc_stream_results): the caller's per-packet arrays, what has been copied to them while the call ran, and the packets that were
@@ -891,7 +891,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "group_size") ctx->group_size = (value == 4 || value == 8 || value == 16) ? (int)value : 0;
     else if (n == "pipeline_chunks") {}  // (round 1: chunks on two streams; a call of the wave kernel now runs as epochs -- accepted, ignored)
     else if (n == "log_capacity") { ctx->log_capacity = std::max<long long>(0, value); ctx->log_capacity_user = true; }
-    else if (n == "log_sets") ctx->log_sets = value == 1 ? 1 : 2;  // 1: the estimator passes of an epoch run before the next epoch, not beside it
+    else if (n == "log_sets") ctx->log_sets = (value == 1 || value == 2) ? (int)value : 0;  // 1: the estimator passes of an epoch run before the next epoch, not beside it; 0: automatic
     else if (n == "chunk_packets") ctx->chunk_packets = std::max<long long>(1024, value);
     else return fail(ctx, TARDIS_MC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
     return TARDIS_MC_OK;
@@ -1788,6 +1788,36 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 wave_lds = mc::wave_kernel_lds_bytes<false, false, true, true>(ctx->n_shells);
             }
             long long log_capacity = ctx->log_capacity;
+            // One log set or two.  Two let the passes of an epoch run on a second stream beside the next launch -- but they do not fit beside sixteen resident waves per CU,
+            // so "beside" means: contending with the next launch's first 0.1 s, both slower for it.  Measured at 1e8 packets (profiles/r06_log_sets.txt): the passes before
+            // the next launch, alone on the chip, are faster in total, and one set leaves room for epochs half as many again (three launches instead of five): -0.5 %.
+            // So a call of many epochs uses one set; shorter calls keep two (the passes of the bulk run beside the drain of the last launch).
+            bool one_set = ctx->log_sets == 1;
+            if (ctx->log_sets == 0 && partition && !vq && !vpk && ctx->drain_split == 0 && ctx->drain_compact == 0 && ctx->epoch_split == 0 && ctx->pass_cus == 0) {
+                double two_set_capacity = (double)ctx->log_capacity;
+                size_t free_b = 0, total_b = 0;
+                if (!ctx->log_capacity_user && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                    const double have = (double)(ctx->log_records[0].cap + ctx->log_records[1].cap + ctx->log_keys[0].cap + ctx->log_keys[1].cap +
+                                                 ctx->log_sorted[0].cap + ctx->log_sorted[1].cap + ctx->log_part.cap);
+                    two_set_capacity = std::min(two_set_capacity, 0.6 * ((double)free_b + have) / 80.0);
+                }
+                // (four epochs or more with two sets; at two or three the passes of the first epochs still find room beside the last launch's drain: 4e7 packets
+                // 1 292 - 1 308 ms with two sets, 1 320 - 1 351 with one)
+                const double per_packet = ctx->traces_per_packet > 0.0 ? 1.05 * ctx->traces_per_packet : ctx->log_budget_per_packet;
+                one_set = (double)n * per_packet > 3.0 * two_set_capacity;
+            }
+            if (one_set && !ctx->log_capacity_user) {
+                // (the second set of an earlier, smaller call is given back first; 24 + 4 bytes per record and the 24 of the scratch copy)
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->stream2) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
+                ctx->log_records[1].release(); ctx->log_keys[1].release(); ctx->log_sorted[1].release(); ctx->log_bins[1].release(); ctx->log_cursor[1].release();
+                size_t free_b = 0, total_b = 0;
+                log_capacity = 4000000000LL;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                    const double have = (double)(ctx->log_records[0].cap + ctx->log_keys[0].cap + ctx->log_sorted[0].cap + ctx->log_part.cap);
+                    log_capacity = std::min<long long>(log_capacity, (long long)(0.6 * ((double)free_b + have) / (partition ? 52.0 : 32.0)));
+                }
+            } else
             if (!ctx->log_capacity_user) {
                 // (fewer, longer epochs are faster -- 25.8 vs 24.5 Mpkt/s at 1e8 packets with 2.5e9 instead of 1.5e9 records per set
                 // -- but two sets of 2.5e9 records are 160 GB: never take more than 60 % of what is free, counting what the log holds already)
@@ -1823,7 +1853,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             const bool may_suspend = region_capacity > 0 || vq;
             // a second buffer set (the estimator passes of an epoch overlap the next epoch) only when the call may need several epochs
             // ... or splits off its drain (WaveCold::drain_split): worth a second launch once the call is long enough for a drain to form
-            const bool want_split = ctx->drain_split && !vq && ctx->log_sets != 1 && region_capacity > 0 && n >= 64LL * waves * 4;
+            const bool want_split = ctx->drain_split && !vq && !one_set && region_capacity > 0 && n >= 64LL * waves * 4;
             // Tail split: the last epoch of a call should hold only the DRAIN (the ~4 % of the records the longest-lived packets log
             // after the packet supply has run out, on a mostly idle chip), so that the passes over everything before it run beside the
             // drain and only the passes of the tail -- milliseconds -- are left for after the call.  The host knows the call's records
@@ -1837,15 +1867,15 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             // after the call before); calls of several epochs +0.5 % (their passes overlap the next epoch already, the extra launch
             // costs) -- so only the former.
             const bool one_epoch = (double)region_capacity * (double)n_chunks >= (double)n * ctx->traces_per_packet * 1.05;
-            const bool tail_plan = ctx->log_tail_split && !vq && ctx->log_sets != 1 && region_capacity > 0 && ctx->traces_per_packet > 0.0 && one_epoch &&
+            const bool tail_plan = ctx->log_tail_split && !vq && !one_set && region_capacity > 0 && ctx->traces_per_packet > 0.0 && one_epoch &&
                                    (double)n * ctx->traces_per_packet >= 5e8 && (double)n * ctx->traces_per_packet > 2.0 * tail_records;
             // (the second buffer set is allocated as soon as a tail split MAY be planned -- the first call of a context has no estimate yet
             // -- so that no later call of the same size allocates tens of GB in the middle of an iteration)
-            const bool tail_possible = ctx->log_tail_split && !vq && ctx->log_sets != 1 && region_capacity > 0 &&
+            const bool tail_possible = ctx->log_tail_split && !vq && !one_set && region_capacity > 0 &&
                                        (double)n * std::max(ctx->traces_per_packet, 16.0) >= 5e8;
             // ... or packs the drain's live lanes into fewer waves (drain_compact): the passes of the launch before run beside the packed drain
-            const bool want_compact = ctx->drain_compact > 0 && !vq && !vpk && !cu_split && !shell_log && ctx->log_sets != 1 && region_capacity > 0 && n > 64LL * (waves - 1) && waves >= 8;
-            const int n_sets = (ctx->log_sets == 1 || vq) ? 1 : ((tail_plan || tail_possible || want_split || want_compact || (region_capacity > 0 && (unsigned long long)region_capacity * n_chunks < (unsigned long long)((double)n * ctx->log_budget_per_packet))) ? 2 : 1);
+            const bool want_compact = ctx->drain_compact > 0 && !vq && !vpk && !cu_split && !shell_log && !one_set && region_capacity > 0 && n > 64LL * (waves - 1) && waves >= 8;
+            const int n_sets = (one_set || vq) ? 1 : ((tail_plan || tail_possible || want_split || want_compact || (region_capacity > 0 && (unsigned long long)region_capacity * n_chunks < (unsigned long long)((double)n * ctx->log_budget_per_packet))) ? 2 : 1);
             bool split_armed = want_split && !want_compact;
             bool compact_armed = want_compact;
             int waves_cur = waves;  // (the grid of the next launch: smaller after a compaction)

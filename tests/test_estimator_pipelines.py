@@ -106,6 +106,16 @@ def test_many_epochs_and_odd_chunks(long_traces, pipeline, accumulate):
     _same(got, ref)
 
 
+@pytest.mark.parametrize("sets", [1, 2])
+def test_passes_before_or_beside_the_next_launch(long_traces, sets):
+    """`log_sets` 1: one log set, the passes of an epoch run before the next launch (what a call of several epochs takes by itself); 2: two sets, the
+    passes run on a second stream beside the next launch.  Both on a log a fifth of what the call writes."""
+    prob, ref = long_traces
+    got, launches, _ = _run(prob, 1, 3, log_sets=sets, log_capacity=100_000, log_chunk_records=512)
+    assert launches >= 4
+    _same(got, ref)
+
+
 @pytest.mark.parametrize("accumulate", [1, 2])
 @pytest.mark.parametrize("options", [dict(), dict(log_capacity=200_000, log_chunk_records=257)], ids=["one-launch", "epochs-odd-chunks"])
 def test_two_level_partition_without_the_shell_sorted_log(long_traces, accumulate, options):
