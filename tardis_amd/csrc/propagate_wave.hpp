@@ -229,8 +229,9 @@ __global__ void __launch_bounds__(64) drain_census_kernel(const LaneSave *__rest
     }
 }
 // live lanes of wave w -> consecutive places of the packed grid (the order is that of the atomics: a packet's results do not depend on its place)
+// (`density`: live lanes per packed wave, <= 64 -- a pass takes longer the more of a wave's lanes are live, and the drain is the chain of its longest packet)
 __global__ void __launch_bounds__(64) drain_compact_kernel(const LaneSave *__restrict__ save, const WaveSave *__restrict__ wsave, const uint32_t *__restrict__ states, int waves,
-                                                           LaneSave *__restrict__ dst_save, uint32_t *__restrict__ dst_states, unsigned *__restrict__ counter)
+                                                           LaneSave *__restrict__ dst_save, uint32_t *__restrict__ dst_states, unsigned *__restrict__ counter, unsigned density)
 {
     const int w = blockIdx.x, lane = threadIdx.x;
     if (w >= waves) return;
@@ -243,24 +244,25 @@ __global__ void __launch_bounds__(64) drain_compact_kernel(const LaneSave *__res
     unsigned base = 0;
     if (lane == 0) base = atomicAdd(counter, (unsigned)__popcll(lm));
     base = (unsigned)__shfl((int)base, 0);
-    if (live) dst_save[base + (unsigned)__popcll(lm & ((1ull << lane) - 1ull))] = save[(size_t)w * 64 + lane];
+    auto place = [density](unsigned g) { return (size_t)(g / density) * 64 + (g % density); };  // g-th live lane of the grid -> its wave and lane
+    if (live) dst_save[place(base + (unsigned)__popcll(lm & ((1ull << lane) - 1ull)))] = save[(size_t)w * 64 + lane];
     // the MT19937 state buffers of the live lanes, one after the other, 64 words at a time
     unsigned k = 0;
     for (unsigned long long m = lm; m; m &= m - 1ull, ++k) {
         const int src_lane = __ffsll((long long)m) - 1;
         const uint32_t *from = states + ((size_t)w * 64 + (size_t)src_lane) * WV_STATE_STRIDE;
-        uint32_t *to = dst_states + (size_t)(base + k) * WV_STATE_STRIDE;
+        uint32_t *to = dst_states + place(base + k) * WV_STATE_STRIDE;
         for (int i = lane; i < WV_STATE_STRIDE; i += 64) to[i] = from[i];
     }
 }
 // the packed grid's wave records, and the idle lanes behind the last live one
 __global__ void __launch_bounds__(256) drain_compact_finish_kernel(LaneSave *__restrict__ dst_save, WaveSave *__restrict__ dst_wsave, const unsigned *__restrict__ counter,
-                                                                  long long n_packets)
+                                                                  long long n_packets, unsigned density)
 {
-    const unsigned total = *counter, waves = (total + 63u) / 64u;
+    const unsigned total = *counter, waves = (total + density - 1u) / density;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= waves * 64u) return;
-    if (i >= total) {
+    if ((i & 63u) >= density || (i >> 6) * density + (i & 63u) >= total) {
         LaneSave idle{};
         idle.state = WS_DONE;
         dst_save[i] = idle;

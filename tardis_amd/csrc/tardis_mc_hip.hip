@@ -237,6 +237,7 @@ struct TardisMcContext {
     // drain compaction (option drain_compact = T: waves suspend once the supply has run out and T or fewer of their lanes are left; the live lanes are packed into
     // full waves and the rest of the call is a launch of fewer waves, beside the estimator passes): the packed grid's buffers, two sets for repeated packing
     int drain_compact = 0;
+    int drain_pack_lanes = 64;  // live lanes per packed wave
     DevBuf lane_save_c[2], wave_save_c[2], seeded_states_c[2], drain_census;
     int compactions = 0;  // of the last propagate call
     DevBuf vq_req, vq_items, vq_count, vq_jsave;  // volley queue (variant 4, propagate_wave.hpp: VolleyRequest)
@@ -854,6 +855,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "drain_split") ctx->drain_split = value ? 1 : 0;
     else if (n == "drain_compact") ctx->drain_compact = (int)std::max<long long>(0, std::min<long long>(48, value));
+    else if (n == "drain_pack_lanes") ctx->drain_pack_lanes = (int)std::max<long long>(1, std::min<long long>(64, value));
     else if (n == "walk_sector_packing") ctx->walk_sector_packing = value ? 1 : 0;
     else if (n == "walk_hot") ctx->walk_hot = value < 0 ? -1 : (value ? 1 : 0);  // (like walk_sector_packing: before set_opacity)
     else if (n == "walk_hot_min_mass") ctx->walk_hot_min_mass = (int)std::max<long long>(0, std::min<long long>(value, 1001));
@@ -2277,7 +2279,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                     HIP_TRY(ctx, hipMemcpyAsync(ctx->suspended_host + 8, cen, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
                     HIP_TRY(ctx, hipStreamSynchronize(st));
                     const unsigned live = ctx->suspended_host[8], reserved = ctx->suspended_host[9], waiting = ctx->suspended_host[11];
-                    const int packed = (int)((live + 63u) / 64u);
+                    const unsigned density = (unsigned)ctx->drain_pack_lanes;
+                    const int packed = (int)((live + density - 1u) / density);
                     // (only when nothing is left to hand out, and when it frees more than half of the grid)
                     if (reserved == 0 && waiting == 0 && live > 0 && 2 * packed <= waves_cur) {
                         const int g = ctx->compactions & 1;
@@ -2286,15 +2289,15 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                         HIP_TRY(ctx, ctx->seeded_states_c[g].ensure((size_t)packed * 64 * mc::WV_STATE_STRIDE * sizeof(uint32_t)));
                         HIP_TRY(ctx, hipMemsetAsync(cen + 4, 0, sizeof(unsigned), st));
                         hipLaunchKernelGGL(mc::drain_compact_kernel, dim3(waves_cur), dim3(64), 0, st, (const mc::LaneSave *)cur_save, (const mc::WaveSave *)cur_wsave,
-                                           (const uint32_t *)cur_states, waves_cur, ctx->lane_save_c[g].as<mc::LaneSave>(), ctx->seeded_states_c[g].as<uint32_t>(), cen + 4);
+                                           (const uint32_t *)cur_states, waves_cur, ctx->lane_save_c[g].as<mc::LaneSave>(), ctx->seeded_states_c[g].as<uint32_t>(), cen + 4, density);
                         HIP_TRY(ctx, hipGetLastError());
                         hipLaunchKernelGGL(mc::drain_compact_finish_kernel, dim3((unsigned)((packed * 64 + 255) / 256)), dim3(256), 0, st, ctx->lane_save_c[g].as<mc::LaneSave>(),
-                                           ctx->wave_save_c[g].as<mc::WaveSave>(), (const unsigned *)(cen + 4), n);
+                                           ctx->wave_save_c[g].as<mc::WaveSave>(), (const unsigned *)(cen + 4), n, density);
                         HIP_TRY(ctx, hipGetLastError());
                         cur_save = ctx->lane_save_c[g].as<mc::LaneSave>(); cur_wsave = ctx->wave_save_c[g].as<mc::WaveSave>(); cur_states = ctx->seeded_states_c[g].as<uint32_t>();
                         waves_cur = packed;
                         ctx->compactions += 1;
-                        if (packed < 2 * cus) compact_armed = false;  // (nothing left worth freeing)
+                        if (packed < 2 * cus || (int)density <= 2 * ctx->drain_compact) compact_armed = false;  // (nothing left worth freeing / the packed waves would suspend again at once)
                     }
                 }
                 if (streaming) {
