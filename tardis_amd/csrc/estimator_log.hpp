@@ -384,10 +384,11 @@ __global__ void __launch_bounds__(64 * ACCB_WAVES, 8) accumulate_blocks_kernel(c
 constexpr int ACCD_WAVES = 16;                                 // one workgroup per CU (100 KB of LDS)
 constexpr int ACCD_TILE = EST_TILE + EST_APRON;                // lines in LDS
 constexpr int ACCD_TOP = 5;                                    // top level: blocks of 32 lines
-constexpr int ACCD_CELLS = 2 * ACCD_TILE - ((2 * ACCD_TILE) >> (ACCD_TOP + 1));  // accumulators per estimator: level l (T >> l cells) lives at [2 T - (2 T >> l), ...)
+constexpr int ACCD_CELLS = 2 * ACCD_TILE;                     // accumulators per estimator, laid out like a bottom-up segment tree: the block of 2^l lines at line p is cell (T + p) >> l
+                                                               // (T a multiple of 2^TOP: level l fills [T >> l, 2 T >> l), the levels do not overlap; cells below T >> TOP are unused)
 constexpr int ACCD_LONG = 255;                                 // longer records are walked by the whole wave
 constexpr int ACCD_PASSES = 20;                                // >= 18 = the items of 64 records of ACCD_LONG lines (<= 5 + 8 + 5 each) / 64
-static_assert(ACCD_TILE % (1 << ACCD_TOP) == 0 && EST_TILE % (1 << ACCD_TOP) == 0, "whole top-level blocks, tiles aligned to them");
+static_assert(ACCD_TILE % 256 == 0 && ACCD_TILE % (1 << ACCD_TOP) == 0 && EST_TILE % (1 << ACCD_TOP) == 0, "whole top-level blocks, tiles aligned to them");
 
 // LOOP: every lane walks its own record from left to right -- at line p the largest aligned block that still fits, min(ctz(p | 32), floor(log2(end - p))): the same
 // blocks as the item list of the balanced form (ascending towards the split point, 32-line blocks across it, descending behind it) without the list: no scan over
@@ -467,12 +468,12 @@ __global__ void __launch_bounds__(64 * ACCD_WAVES) accumulate_dyadic_kernel(cons
             }
             const unsigned last = pos + (1u << level) - 1u;  // the last line the item covers
             if (last < tile_len) {
-                const unsigned idx = 2u * ACCD_TILE - ((2u * ACCD_TILE) >> level) + (pos >> level);
+                const unsigned idx = ((unsigned)ACCD_TILE + pos) >> level;
                 atomicAdd(&acc_jb[idx], c_jb);
                 atomicAdd(&acc_ed[idx], c_e);
             } else {
                 for (unsigned k = pos; k <= last; ++k) {
-                    if (k < tile_len) { atomicAdd(&acc_jb[k], c_jb); atomicAdd(&acc_ed[k], c_e); }
+                    if (k < tile_len) { atomicAdd(&acc_jb[ACCD_TILE + k], c_jb); atomicAdd(&acc_ed[ACCD_TILE + k], c_e); }
                     else far_line(k, c_jb, c_e);
                 }
             }
@@ -510,16 +511,17 @@ __global__ void __launch_bounds__(64 * ACCD_WAVES) accumulate_dyadic_kernel(cons
                 const LineVisitRecord rec = next;
                 next = next2;
                 next2 = fetch(base + 2 * stride + (unsigned)lane);
-                unsigned p = rec.idx0 - tile_idx0;
-                const unsigned e = rec.n > (unsigned)ACCD_LONG ? p : p + rec.n;
+                // (q = T + line: T is a multiple of 256, so q's low bits are the line's, and the cell of a block is q >> level)
+                unsigned q = (unsigned)ACCD_TILE + (rec.idx0 - tile_idx0);
+                const unsigned e = rec.n > (unsigned)ACCD_LONG ? q : q + rec.n;
                 const double cj = rec.c_jb, ce = rec.c_e;
-                while (p < e) {
-                    const unsigned fit = 31u - (unsigned)__builtin_clz(e - p);
-                    const unsigned lv = min((unsigned)__builtin_ctz(p | (1u << ACCD_TOP)), fit);
-                    const unsigned idx = 2u * ACCD_TILE - ((2u * ACCD_TILE) >> lv) + (p >> lv);
+                while (q < e) {
+                    const unsigned fit = 31u - (unsigned)__builtin_clz(e - q);
+                    const unsigned lv = min((unsigned)__builtin_ctz(q | (1u << ACCD_TOP)), fit);
+                    const unsigned idx = q >> lv;
                     atomicAdd(&acc_jb[idx], cj);
                     atomicAdd(&acc_ed[idx], ce);
-                    p += 1u << lv;
+                    q += 1u << lv;
                 }
                 long_records(rec);
             }
@@ -577,10 +579,10 @@ __global__ void __launch_bounds__(64 * ACCD_WAVES) accumulate_dyadic_kernel(cons
         __syncthreads();
         for (unsigned k = threadIdx.x; k < tile_len; k += 64 * ACCD_WAVES) {
             const double f = FULL ? 1.0 : nu_line[tile_idx0 - row + k];
-            double v_jb = acc_jb[k], v_ed = acc_ed[k];
+            double v_jb = acc_jb[ACCD_TILE + k], v_ed = acc_ed[ACCD_TILE + k];
 #pragma unroll
             for (unsigned l = 1; l <= (unsigned)ACCD_TOP; ++l) {
-                const unsigned idx = 2u * ACCD_TILE - ((2u * ACCD_TILE) >> l) + (k >> l);
+                const unsigned idx = ((unsigned)ACCD_TILE + k) >> l;
                 v_jb += acc_jb[idx]; v_ed += acc_ed[idx];
             }
             if (v_jb != 0.0) atomic_add_f64(&jblue_t[tile_idx0 + k], v_jb * f);

@@ -174,13 +174,17 @@ def test_dyadic_items_tile_a_trace_with_aligned_blocks():
 
 
 def test_dyadic_cells_and_flush():
-    """Level l of the accumulators lives at [2 T - (2 T >> l), ...): the levels do not overlap, and a line's flush -- the sum of the six
-    cells above it -- counts every trace over the line exactly once."""
+    """The accumulators are laid out like a bottom-up segment tree: the block of 2^l lines at line p is cell (T + p) >> l.  T is a multiple of 2^TOP, so the
+    levels do not overlap (level l fills [T >> l, 2 T >> l)), and a line's flush -- the sum of the six cells above it -- counts every trace over the line
+    exactly once."""
     T = TILE + APRON
-    cells = 2 * T - ((2 * T) >> (TOP + 1))
-    off = [2 * T - ((2 * T) >> l) for l in range(TOP + 1)]
+    assert T % 256 == 0
+    cells = 2 * T
     for l in range(TOP + 1):
-        assert off[l] + (T >> l) == (off[l + 1] if l < TOP else cells)
+        lo, hi = T >> l, (2 * T) >> l
+        assert (T + 0) >> l == lo and (T + T - 1) >> l == hi - 1
+        if l < TOP:
+            assert (T >> (l + 1), (2 * T) >> (l + 1)) == (lo >> 1, lo)  # the next level ends where this one begins
     rng = np.random.default_rng(3)
     acc = np.zeros(cells)
     truth = np.zeros(T)
@@ -190,11 +194,13 @@ def test_dyadic_cells_and_flush():
         m = bin(up & 31).count("1") + (up >> 5) + (dn >> 5) + bin(dn & 31).count("1")
         for j in range(m):
             level, pos = _dyadic_item(a, up, dn, j)
-            acc[off[level] + (pos >> level)] += 1.0
+            assert pos % (1 << level) == 0
+            acc[(T + pos) >> level] += 1.0
         truth[a:a + n] += 1.0
     k = np.arange(T)
-    got = sum(acc[off[l] + (k >> l)] for l in range(TOP + 1))
+    got = sum(acc[(T + k) >> l] for l in range(TOP + 1))
     assert np.array_equal(got, truth)
+    assert not acc[:T >> TOP].any()
 
 
 def test_the_greedy_walk_visits_the_items_blocks():
