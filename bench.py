@@ -421,14 +421,15 @@ def roofline_block(eng, counters: dict, ktimes: dict, last_ms: float, P: int, tr
             "kernel": f"{dominant} (dominant kernel of a step)", "kernel_ms": kernel_ms,
             "launches_per_step": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
             "note": "kernel_ms = mean HIP-event duration of the step's propagation launches (the epochs of one "
-                    "tardis_mc_propagate call, back to back on the engine's stream; the estimator passes of an epoch run "
-                    "on a second stream); macro-atom term of the byte model: min(8 B x rows examined, 64 B x jumps), see walk_bytes()",
+                    "tardis_mc_propagate call on the engine's stream; the estimator passes of an epoch run between the launches -- calls of "
+                    "four epochs or more, one log set -- or on a second stream beside the next launch); macro-atom term of the byte model: "
+                    "min(8 B x rows examined, 64 B x jumps), see walk_bytes()",
             "step": {"algorithmic_bytes": step_bytes, "device_ms": last_ms, "achieved": step_achieved,
                      "frac": step_achieved / HBM_PEAK_GBS, "seed_kernel_ms": ktimes["seed_ms"],
                      "estimator_passes_ms": ktimes.get("estimator_ms", 0.0),
                      "note": "all kernels of one iteration: launch preparation, propagation, line-estimator passes; estimator_passes_ms is the "
-                             "ELAPSED time of the passes' stream -- their workgroups wait for CUs behind the next epoch's waves -- not their "
-                             "work (~85 ms per epoch of 2e9 records, profiles/r04_estimator_partition.txt)"},
+                             "elapsed time of the passes: their work where they run between the launches (one log set: ~75 ms per 1.8e9 records, "
+                             "profiles/r06_log_sets.txt), mostly waiting for CUs where they run on the second stream beside the next launch"},
             "per_packet": dict({k: counters[k] / max(P, 1) for k in ("line_visits", "events", "macro_transitions", "rng_draws",
                                                                       "vpackets", "vpacket_line_visits")},
                                **({"vpacket_crossings_traced": crossings / max(P, 1)} if crossings else {}))}

@@ -1884,10 +1884,19 @@ int tardis_mc_propagate(TardisMcContext *ctx)
             mc::LaneSave *cur_save = nullptr; mc::WaveSave *cur_wsave = nullptr; uint32_t *cur_states = nullptr;  // (set below, once the buffers exist)
             ctx->compactions = 0;
             const size_t set_records = (size_t)std::max<unsigned long long>((unsigned long long)region_capacity * n_chunks, 1);
+            // (a two-set call on a context whose first set was sized by a larger one-set call: both sets lie in the first set's buffers -- a second allocation of
+            // tens of GB costs ~1 s the first time, the memory is cleared)
+            const bool set1_inside = n_sets == 2 && !ctx->log_records[1].p && ctx->log_records[0].cap >= 2 * set_records * sizeof(mc::LineVisitRecord) &&
+                                     ctx->log_keys[0].cap >= 2 * set_records * sizeof(unsigned) && (partition || ctx->log_sorted[0].cap >= 2 * set_records * sizeof(unsigned));
+            auto set_records_ptr = [&](int b) { return set1_inside ? ctx->log_records[0].as<mc::LineVisitRecord>() + (size_t)b * set_records : ctx->log_records[b].as<mc::LineVisitRecord>(); };
+            auto set_keys_ptr = [&](int b) { return set1_inside ? ctx->log_keys[0].as<unsigned>() + (size_t)b * set_records : ctx->log_keys[b].as<unsigned>(); };
+            auto set_sorted_ptr = [&](int b) { return set1_inside ? ctx->log_sorted[0].as<unsigned>() + (size_t)b * set_records : ctx->log_sorted[b].as<unsigned>(); };
             for (int b = 0; b < n_sets; ++b) {
-                HIP_TRY(ctx, ctx->log_records[b].ensure(set_records * sizeof(mc::LineVisitRecord)));
-                HIP_TRY(ctx, ctx->log_keys[b].ensure(set_records * sizeof(unsigned)));
-                if (!partition) HIP_TRY(ctx, ctx->log_sorted[b].ensure(set_records * sizeof(unsigned)));
+                if (!(set1_inside && b == 1)) {
+                    HIP_TRY(ctx, ctx->log_records[b].ensure(set_records * sizeof(mc::LineVisitRecord)));
+                    HIP_TRY(ctx, ctx->log_keys[b].ensure(set_records * sizeof(unsigned)));
+                    if (!partition) HIP_TRY(ctx, ctx->log_sorted[b].ensure(set_records * sizeof(unsigned)));
+                }
                 HIP_TRY(ctx, ctx->log_bins[b].ensure((size_t)(4 * (n_bins + 2) + ctx->n_shells + 2) * sizeof(unsigned)));
                 HIP_TRY(ctx, ctx->log_cursor[b].ensure((size_t)(n_chunks + 2) * sizeof(unsigned)));  // chunk counts | pool counter
             }
@@ -1977,7 +1986,7 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 if (lg.region_capacity == 0) return hipSuccess;
                 unsigned *bin_count = ctx->log_bins[b].as<unsigned>(), *bin_start = bin_count + (n_bins + 1),
                          *bin_fill = bin_start + (n_bins + 1), *slice_start = bin_fill + (n_bins + 1);
-                unsigned *sorted = ctx->log_sorted[b].as<unsigned>();
+                unsigned *sorted = set_sorted_ptr(b);
                 hipError_t e = hipMemsetAsync(bin_count, 0, (size_t)(n_bins + 1) * sizeof(unsigned), es);
                 if (e != hipSuccess) return e;
                 const size_t hist_lds = (size_t)n_bins * sizeof(unsigned);
@@ -2124,8 +2133,8 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                 }
                 mc::EstimatorLog lg{};
                 lg.tiles_per_shell = tiles;
-                lg.records = ctx->log_records[b].as<mc::LineVisitRecord>();
-                lg.keys = ctx->log_keys[b].as<unsigned>();
+                lg.records = set_records_ptr(b);
+                lg.keys = set_keys_ptr(b);
                 unsigned long long pool_chunks = n_chunks;
                 if (tail_plan) {
                     const double bulk = records_est - records_done - tail_records;  // what is left before the tail

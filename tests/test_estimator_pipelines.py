@@ -116,6 +116,27 @@ def test_passes_before_or_beside_the_next_launch(long_traces, sets):
     _same(got, ref)
 
 
+def test_two_sets_inside_the_buffers_of_a_larger_one_set_call(oracle, long_traces):
+    """A context that has run a larger call on ONE log set places the two sets of a later, smaller call inside that set's buffers (no second allocation of
+    tens of GB in the middle of a run): the smaller call -- many epochs, the passes of one beside the launch of the next -- still gives the oracle's sums."""
+    from tardis_amd.engine import Engine
+    prob, ref = long_traces
+    big = synthetic.make_problem(seed=6, n_packets=120_000, n_shells=8, n_lines=400_000, line_interaction_type="macroatom", log_tau_mean=-5.0)
+    with Engine(0) as eng:
+        eng.set_option("track_last_interaction", 0)
+        eng.set_option("log_sets", 1)
+        eng.set_geometry(big.geometry, big.time_explosion); eng.set_opacity(big.opacity_state)
+        eng.set_config(big.montecarlo_configuration, big.spectrum_frequency_grid); eng.set_packets(big.packet_collection)
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        eng.set_option("log_sets", 2); eng.set_option("log_capacity", 150_000); eng.set_option("log_chunk_records", 512)
+        eng.set_geometry(prob.geometry, prob.time_explosion); eng.set_opacity(prob.opacity_state)
+        eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid); eng.set_packets(prob.packet_collection)
+        eng.reset_estimators(); eng.propagate(); eng.synchronize()
+        got = eng.get_results(track_last_interaction=False)
+        assert eng.last_kernel_times()["launches"] >= 3
+    _same(got, ref)
+
+
 @pytest.mark.parametrize("accumulate", [1, 2])
 @pytest.mark.parametrize("options", [dict(), dict(log_capacity=200_000, log_chunk_records=257)], ids=["one-launch", "epochs-odd-chunks"])
 def test_two_level_partition_without_the_shell_sorted_log(long_traces, accumulate, options):
