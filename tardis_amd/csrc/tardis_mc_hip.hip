@@ -238,6 +238,7 @@ struct TardisMcContext {
     // full waves and the rest of the call is a launch of fewer waves, beside the estimator passes): the packed grid's buffers, two sets for repeated packing
     int drain_compact = 0;
     int drain_pack_lanes = 64;  // live lanes per packed wave
+    int est_one_level = 1;      // the passes' partition in one pass where the (shell, tile) bins are few enough to be ranked in LDS at once (0: always two levels)
     DevBuf lane_save_c[2], wave_save_c[2], seeded_states_c[2], drain_census;
     int compactions = 0;  // of the last propagate call
     DevBuf vq_req, vq_items, vq_count, vq_jsave;  // volley queue (variant 4, propagate_wave.hpp: VolleyRequest)
@@ -855,6 +856,7 @@ int tardis_mc_set_option(TardisMcContext *ctx, const char *name, long long value
     else if (n == "debug_flags") ctx->debug_flags = (int)value;
     else if (n == "drain_split") ctx->drain_split = value ? 1 : 0;
     else if (n == "drain_compact") ctx->drain_compact = (int)std::max<long long>(0, std::min<long long>(48, value));
+    else if (n == "est_one_level") ctx->est_one_level = value ? 1 : 0;
     else if (n == "drain_pack_lanes") ctx->drain_pack_lanes = (int)std::max<long long>(1, std::min<long long>(64, value));
     else if (n == "walk_sector_packing") ctx->walk_sector_packing = value ? 1 : 0;
     else if (n == "walk_hot") ctx->walk_hot = value < 0 ? -1 : (value ? 1 : 0);  // (like walk_sector_packing: before set_opacity)
@@ -2005,6 +2007,13 @@ int tardis_mc_propagate(TardisMcContext *ctx)
                     mc::LineVisitRecord *scratch = ctx->log_part.as<mc::LineVisitRecord>();
                     auto bits_of = [](int n) { int b = 0; while ((1 << b) < n) ++b; return b; };
                     const mc::LineVisitRecord *binned = lg.records;  // what the accumulate kernel reads
+                    if (!shell_log && ctx->est_one_level != 0 && n_bins <= mc::PART_LOCAL_BUCKETS) {
+                        // few bins (short line lists: 300 on the tardis_example tables): ONE partition pass, log chunks -> scratch copy by bin.  (partition_kernel<2> with
+                        // "one shell of n_bins tiles": every chunk's first bucket is bin 0, a staged segment ranks over all bins)
+                        hipLaunchKernelGGL(mc::partition_kernel<2>, dim3(cus * 2), dim3(mc::PART_THREADS), 0, es, lg.records, lg.keys, lg.region_count, lg.n_regions,
+                                           lg.region_capacity, (const unsigned *)nullptr, n_bins, ctx->n_lines, bits_of(n_bins), bin_fill, scratch);
+                        binned = scratch;
+                    } else
                     if (shell_log) {  // the chunks hold one shell each: straight to the partition by bin, into the scratch copy
                         hipLaunchKernelGGL(mc::partition_kernel<2>, dim3(cus * 2), dim3(mc::PART_THREADS), 0, es, lg.records, lg.keys, lg.region_count, lg.n_regions,
                                            lg.region_capacity, (const unsigned *)nullptr, lg.tiles_per_shell, ctx->n_lines, bits_of(mc::PART_LOCAL_BUCKETS), bin_fill, scratch);

@@ -116,6 +116,19 @@ def test_passes_before_or_beside_the_next_launch(long_traces, sets):
     _same(got, ref)
 
 
+@pytest.mark.parametrize("one_level", [1, 0])
+@pytest.mark.parametrize("options", [dict(), dict(log_capacity=300_000, log_chunk_records=300)], ids=["one-launch", "epochs"])
+def test_few_bins_take_one_partition_pass(oracle, one_level, options):
+    """Short line lists (3e4 lines: 15 tiles x 20 shells = 300 bins, the tardis_example shape) rank all bins of a staged segment in LDS at once: one partition
+    pass, log chunks -> scratch copy by bin, instead of two (`est_one_level` 0 keeps the two).  Same sums."""
+    prob = synthetic.make_problem(seed=17, n_packets=60_000, n_shells=20, n_lines=30_000, line_interaction_type="downbranch")
+    ref, _ = _oracle(oracle, prob)
+    for accumulate in (3, 1):
+        got, launches, variant = _run(prob, 1, accumulate, est_one_level=one_level, **options)
+        assert variant == 3 and (launches >= 3 if options else launches == 1)
+        _same(got, ref)
+
+
 def test_two_sets_inside_the_buffers_of_a_larger_one_set_call(oracle, long_traces):
     """A context that has run a larger call on ONE log set places the two sets of a later, smaller call inside that set's buffers (no second allocation of
     tens of GB in the middle of a run): the smaller call -- many epochs, the passes of one beside the launch of the next -- still gives the oracle's sums."""

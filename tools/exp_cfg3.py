@@ -36,7 +36,7 @@ eng.set_config(prob.montecarlo_configuration, prob.spectrum_frequency_grid)
 defaults = {"log_tail_split": 1, "log_tail_packets": 8, "variant": -1, "debug_flags": 0, "group_size": 0, "lane_sweep_min_active": -1, "walk_min_active": -2, "lane_sweep_max_steps": 1 << 30, "waves_per_simd": 4,
             "track_last_interaction": 1, "walk_hot": -1, "walk_hot_min_mass": int(os.environ.get("EXP_HOT_SHORT", 800)),
             "walk_hot_min_mass_long": int(os.environ.get("EXP_HOT_LONG", 400)), "walk_sector_packing": 1,
-            "vp_carry_min_active": 16, "pass_cus": 0, "bucket_lines_permille": 750, "vpk_wide_registers": 1, "ls_waves_per_simd": 4, "sweep_table": -1, "log_sets": 0, "est_accumulate": 3, "est_pipeline": 1, "epoch_split": 0, "log_by_shell": 0, "drain_compact": 0, "drain_split": 0, "drain_pack_lanes": 64}  # (4: the 128-VGPR lane-sweep instantiation, so that A/B lines compare like with like; 0 = the engine's own choice)
+            "vp_carry_min_active": 16, "pass_cus": 0, "bucket_lines_permille": 750, "vpk_wide_registers": 1, "ls_waves_per_simd": 4, "sweep_table": -1, "log_sets": 0, "est_accumulate": 3, "est_pipeline": 1, "epoch_split": 0, "log_by_shell": 0, "drain_compact": 0, "drain_split": 0, "drain_pack_lanes": 64, "est_one_level": 1}  # (4: the 128-VGPR lane-sweep instantiation, so that A/B lines compare like with like; 0 = the engine's own choice)
 TABLE_OPTIONS = ("walk_hot", "walk_hot_min_mass", "walk_hot_min_mass_long", "walk_sector_packing", "bucket_lines_permille")  # take effect in set_opacity
 table_state = (-1, 800, 400, 1, 750)  # the engine's defaults, in force for the set_opacity above
 ref = None
