@@ -86,6 +86,16 @@ def test_thresholds(oracle, threshold):
     _same(got, ref)
 
 
+@pytest.mark.parametrize("threshold,density", [(2, 8), (4, 16), (1, 2), (8, 3)])
+def test_sparse_packing(oracle, threshold, density):
+    """`drain_pack_lanes` D: the packed waves hold D live lanes each instead of 64 (the packed grid is not re-armed where its waves would suspend again at once)."""
+    prob = synthetic.make_problem(**PROBLEMS[2])
+    ref = _oracle(oracle, prob)
+    got, packed, launches, _, _ = _run(prob, drain_compact=threshold, drain_pack_lanes=density)
+    assert launches >= 2 and packed >= (1 if threshold * 64 <= 32 * density else 0)
+    _same(got, ref)
+
+
 def test_packing_between_epochs_and_with_streamed_results(oracle):
     """A log too small for the call (many epochs; a launch can end with some waves out of log space and others out of packets), result streaming on: the
     ranges copied early and the late list -- taken from the PACKED grid after a compaction -- give the same arrays."""
